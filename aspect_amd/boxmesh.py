@@ -1,0 +1,299 @@
+"""Structured box mesh hierarchy -> flat tables for the C-ABI.
+
+The reference keeps deal.II/p4est for mesh, DoF and constraint handling
+(stokes_matrix_free_local_smoothing.cc:1548-1878, ``setup_dofs``) and hands
+MatrixFree the cell->DoF tables, constraints and mapping data.  Neither
+deal.II nor p4est exists in this image, so this module is the stand-in host:
+it produces exactly the flat tables the glue of INTEGRATION.md would flatten
+out of ``MatrixFree`` for a box with a multigrid hierarchy
+of uniformly refined levels:
+
+* cells in hierarchical (Morton) order inside each coarse cell, so the
+  children of cell ``P`` on level ``l-1`` are cells ``2^dim*P + c`` on level
+  ``l`` (p4est/deal.II child order: bit0 -> x, bit1 -> y, bit2 -> z);
+* Q2 velocity nodes / Q1 pressure nodes numbered lexicographically on the
+  level grid; velocity DoF = ``dim*node + component``;
+* per-node constraint bit masks (bit c: component c is a homogeneous
+  Dirichlet row: zero velocity -> all bits, axis-aligned no-normal-flux ->
+  the normal component only; local_smoothing.cc:1597-1620, 1675-1698,
+  1794-1821);
+* Cartesian geometry (MappingCartesian, core.cc:118-119): cell extents.
+
+Element conventions follow SURVEY.md A.1: lexicographic cell-local DoF order,
+Gauss-3 quadrature per direction for every operator.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ---------------------------------------------------------------------------
+# Reference element
+# ---------------------------------------------------------------------------
+GAUSS3_X = np.array([0.5 - 0.5 * np.sqrt(0.6), 0.5, 0.5 + 0.5 * np.sqrt(0.6)])
+GAUSS3_W = np.array([5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0])
+
+
+def q2_shape(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.stack([(1 - x) * (1 - 2 * x), 4 * x * (1 - x), x * (2 * x - 1)], axis=-1)
+
+
+def q2_dshape(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.stack([4 * x - 3, 4 - 8 * x, 4 * x - 1], axis=-1)
+
+
+def q1_shape(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.stack([1 - x, x], axis=-1)
+
+
+N2 = q2_shape(GAUSS3_X)    # [q][i]
+D2 = q2_dshape(GAUSS3_X)   # [q][i]
+N1 = q1_shape(GAUSS3_X)    # [q][i]
+
+
+def tensor_shape(mats):
+    """Tensor-product shape table [q_lex][i_lex] with x fastest."""
+    out = mats[0]
+    for m in mats[1:]:
+        out = np.kron(m, out)
+    return out
+
+
+def _morton_decode(m, dim, nbits):
+    coords = [np.zeros_like(m) for _ in range(dim)]
+    for k in range(nbits):
+        for d in range(dim):
+            coords[d] |= ((m >> (dim * k + d)) & 1) << k
+    return coords
+
+
+BC_NONE, BC_ZERO, BC_TANGENTIAL = 0, 1, 2
+
+
+class Level:
+    """Flat tables of one mesh level (what ``agmg_level_desc`` carries)."""
+
+    def __init__(self, dim, extents, reps, l, bc):
+        self.dim = dim
+        self.level = l
+        self.extents = np.asarray(extents, dtype=np.float64)
+        self.reps = np.asarray(reps, dtype=np.int64)
+        self.ncd = self.reps * (1 << l)              # cells per direction
+        self.n_cells = int(np.prod(self.ncd))
+        self.h = self.extents / self.ncd
+        per_coarse = 1 << (dim * l)
+        ids = np.arange(self.n_cells, dtype=np.int64)
+        coarse = ids // per_coarse
+        local = _morton_decode(ids % per_coarse, dim, l)
+        cc = []
+        rem = coarse
+        for d in range(dim):
+            cc.append(rem % self.reps[d])
+            rem = rem // self.reps[d]
+        self.cell_ijk = np.stack([cc[d] * (1 << l) + local[d] for d in range(dim)], axis=1)
+
+        # velocity (Q2) nodes
+        self.nvd = 2 * self.ncd + 1
+        self.n_nodes_v = int(np.prod(self.nvd))
+        self.npd = self.ncd + 1
+        self.n_nodes_p = int(np.prod(self.npd))
+        self.cell_nodes_v = self._cell_nodes(3, 2, self.nvd)
+        self.cell_nodes_p = self._cell_nodes(2, 1, self.npd)
+        self.cmask_v = self._constraint_mask(bc)
+        self.cmask_p = np.zeros(self.n_nodes_p, dtype=np.uint8)
+        self.cell_h = np.tile(self.h, (self.n_cells, 1))
+
+    # -- tables -----------------------------------------------------------
+    def _cell_nodes(self, n1, stride, nd):
+        dim = self.dim
+        loc = np.indices((n1,) * dim).reshape(dim, -1)[::-1]  # x fastest
+        strides = np.ones(dim, dtype=np.int64)
+        for d in range(1, dim):
+            strides[d] = strides[d - 1] * nd[d - 1]
+        out = np.zeros((self.n_cells, n1 ** dim), dtype=np.int64)
+        for d in range(dim):
+            out += (stride * self.cell_ijk[:, d:d + 1] + loc[d][None, :]) * strides[d]
+        return out.astype(np.uint32)
+
+    def node_coords_v(self):
+        idx = np.indices(tuple(self.nvd[::-1])).reshape(self.dim, -1)[::-1]
+        return np.stack([idx[d] * (self.h[d] / 2) for d in range(self.dim)], axis=1)
+
+    def node_coords_p(self):
+        idx = np.indices(tuple(self.npd[::-1])).reshape(self.dim, -1)[::-1]
+        return np.stack([idx[d] * self.h[d] for d in range(self.dim)], axis=1)
+
+    def _constraint_mask(self, bc):
+        """bc: list of 2*dim codes in deal.II box boundary-id order
+        (0: x-, 1: x+, 2: y-, 3: y+, 4: z-, 5: z+; geometry_model/box.cc)."""
+        dim = self.dim
+        idx = np.indices(tuple(self.nvd[::-1])).reshape(dim, -1)[::-1]
+        mask = np.zeros(self.n_nodes_v, dtype=np.uint8)
+        allbits = (1 << dim) - 1
+        for d in range(dim):
+            for side in range(2):
+                code = bc[2 * d + side]
+                on = idx[d] == (0 if side == 0 else self.nvd[d] - 1)
+                if code == BC_ZERO:
+                    mask[on] |= allbits
+                elif code == BC_TANGENTIAL:
+                    mask[on] |= (1 << d)
+        return mask
+
+    def qpoint_coords(self):
+        """Physical coordinates of the 3^dim Gauss points, [n_cells][nq][dim]."""
+        dim = self.dim
+        q = np.indices((3,) * dim).reshape(dim, -1)[::-1]
+        out = np.zeros((self.n_cells, 3 ** dim, dim))
+        for d in range(dim):
+            out[:, :, d] = (self.cell_ijk[:, d:d + 1] + GAUSS3_X[q[d]][None, :]) * self.h[d]
+        return out
+
+    def cell_centers(self):
+        return (self.cell_ijk + 0.5) * self.h[None, :]
+
+    @property
+    def n_dofs_v(self):
+        return self.dim * self.n_nodes_v
+
+    @property
+    def n_dofs_p(self):
+        return self.n_nodes_p
+
+    def constrained_dofs_v(self):
+        """Boolean [n_dofs_v] mask of constrained velocity DoFs."""
+        bits = (self.cmask_v[:, None] >> np.arange(self.dim)[None, :]) & 1
+        return bits.reshape(-1).astype(bool)
+
+
+class BoxHierarchy:
+    """Levels 0..refinement of a box; level ``refinement`` is also the active mesh."""
+
+    def __init__(self, dim, refinement, extents=None, reps=None, bc=None):
+        self.dim = dim
+        extents = [1.0] * dim if extents is None else extents
+        reps = [1] * dim if reps is None else reps
+        bc = [BC_TANGENTIAL] * (2 * dim) if bc is None else bc
+        self.bc = list(bc)
+        self.levels = [Level(dim, extents, reps, l, bc) for l in range(refinement + 1)]
+
+    @property
+    def finest(self):
+        return self.levels[-1]
+
+    @property
+    def n_levels(self):
+        return len(self.levels)
+
+
+# ---------------------------------------------------------------------------
+# Coefficient tables (local_smoothing.cc:172-445, utilities.cc:2697-2770,
+# material_model/interface.cc:542-561)
+# ---------------------------------------------------------------------------
+AVG_NONE = "none"
+AVG_HARMONIC = "harmonic average only viscosity"
+AVG_PROJECT_Q1 = "project to Q1 only viscosity"
+
+
+def _dgq1_tables(dim):
+    """Cellwise L2 projection q-values -> DGQ1 nodal values and back."""
+    Nq = tensor_shape([N1] * dim)                      # [q][i]
+    W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1)
+    M = Nq.T @ (W[:, None] * Nq)
+    proj = np.linalg.solve(M, Nq.T * W[None, :])       # [i][q]
+    return Nq, proj
+
+
+def _dgq1_restriction(dim):
+    """FE_DGQ(1) child->parent restriction = L2 projection of the piecewise
+    child function onto the parent (deal.II FETools::compute_projection_matrices).
+    Returns R[child][i_parent][j_child]."""
+    xg, wg = np.polynomial.legendre.leggauss(4)
+    xg = 0.5 * (xg + 1)
+    wg = 0.5 * wg
+    M1 = np.array([[1 / 3, 1 / 6], [1 / 6, 1 / 3]])
+    R1 = []
+    for c in range(2):
+        xp = 0.5 * (xg + c)        # parent coordinate of child quadrature point
+        rhs = (q1_shape(xp) * (0.5 * wg)[:, None]).T @ q1_shape(xg)   # [i_parent][j_child]
+        R1.append(np.linalg.solve(M1, rhs))
+    out = []
+    for c in range(1 << dim):
+        mats = [R1[(c >> d) & 1] for d in range(dim)]
+        out.append(tensor_shape(mats))
+    return np.stack(out)
+
+
+def viscosity_tables(hier, eta_func, averaging):
+    """Return (active_table, [level tables], eta_min, eta_max).
+
+    Tables are ``[n_cells][1]`` (DGQ0) or ``[n_cells][3^dim]`` (per q-point)
+    exactly as OperatorCellData::viscosity's second extent
+    (matrix_free_operators.h:126-131).
+    """
+    dim = hier.dim
+    fin = hier.finest
+    eta_q = eta_func(fin.qpoint_coords().reshape(-1, dim)).reshape(fin.n_cells, -1)
+    eta_min, eta_max = float(eta_q.min()), float(eta_q.max())
+    nL = hier.n_levels
+    ch = 1 << dim
+    if averaging == AVG_HARMONIC:
+        # unweighted harmonic mean N / sum(1/eta_q), interface.cc:542-561;
+        # min/max are taken AFTER averaging (local_smoothing.cc:247-275)
+        cellv = eta_q.shape[1] / np.sum(1.0 / eta_q, axis=1)
+        eta_min, eta_max = float(cellv.min()), float(cellv.max())
+        active = cellv[:, None].copy()
+        levels = [None] * nL
+        cur = cellv
+        levels[nL - 1] = cur[:, None].copy()
+        for l in range(nL - 2, -1, -1):
+            # FE_DGQ(0) restriction: arithmetic mean of the children
+            cur = cur.reshape(-1, ch).mean(axis=1)
+            levels[l] = cur[:, None].copy()
+        return active, levels, eta_min, eta_max
+    if averaging == AVG_NONE:
+        # fe_projection is DGQ0 (local_smoothing.cc:101-113): the active table
+        # keeps the raw q-point values (:255-266), the level tables come from
+        # the cellwise L2 projection onto a constant = JxW-weighted mean
+        # (utilities.cc:2697-2770), then child means.
+        W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1)
+        cur = eta_q @ W
+        levels = [None] * nL
+        levels[nL - 1] = cur[:, None].copy()
+        for l in range(nL - 2, -1, -1):
+            cur = cur.reshape(-1, ch).mean(axis=1)
+            levels[l] = cur[:, None].copy()
+        return eta_q.copy(), levels, eta_min, eta_max
+    if averaging == AVG_PROJECT_Q1:
+        Nq, proj = _dgq1_tables(dim)
+        nodal = eta_q @ proj.T                         # [cell][2^dim]
+        R = _dgq1_restriction(dim)
+        levels = [None] * nL
+        cur = nodal
+        for l in range(nL - 1, -1, -1):
+            if l < nL - 1:
+                child = cur.reshape(-1, ch, ch)        # [parent][child][j]
+                cur = np.einsum("cij,pcj->pi", R, child)
+            levels[l] = np.clip(cur @ Nq.T, eta_min, eta_max)
+        return levels[nL - 1].copy(), levels, eta_min, eta_max
+    raise ValueError(averaging)
+
+
+# ---------------------------------------------------------------------------
+# Right-hand side  f_u = int rho g . phi_u  (assemblers/stokes.cc:433-442)
+# ---------------------------------------------------------------------------
+def assemble_rhs_u(level, force_func):
+    """force_func(x[n,dim]) -> rho*g [n,dim]; constrained rows are zeroed."""
+    dim = level.dim
+    xq = level.qpoint_coords()
+    f = force_func(xq.reshape(-1, dim)).reshape(level.n_cells, -1, dim)
+    W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(level.h)
+    Nq = tensor_shape([N2] * dim)                      # [q][i]
+    loc = np.einsum("qi,q,cqd->cid", Nq, W, f)         # [cell][i][d]
+    out = np.zeros((level.n_nodes_v, dim))
+    np.add.at(out, level.cell_nodes_v.astype(np.int64), loc)
+    out = out.reshape(-1)
+    out[level.constrained_dofs_v()] = 0.0
+    return out

@@ -1,0 +1,169 @@
+"""Synthetic problem definitions restating the reference's input decks
+(SURVEY.md App. C): material/density/gravity functions, boundary conditions,
+pressure scaling and solver parameters for the BASELINE.json configs and for
+the golden-pinned regression tests of SURVEY.md section 4.
+
+Everything here is host-side input generation (the part ASPECT's material and
+geometry plugins do); the outputs are the flat tables the C-ABI consumes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import boxmesh as bm
+
+# first 8 of the 75 sinker centres, benchmarks/nsinker/nsinker.cc:203-210
+NSINKER_CENTERS = np.array([
+    [0.24257829890, 0.013469574514, 0.38313885004],
+    [0.41465269048, 0.067768972864, 0.99312692973],
+    [0.48430804651, 0.76533776604, 0.031833815403],
+    [0.030935481671, 0.93264044027, 0.88787953411],
+    [0.59132973039, 0.47877868473, 0.83335433660],
+    [0.18633519681, 0.73565270739, 0.11505317181],
+    [0.69865863058, 0.35560411138, 0.63830000658],
+    [0.90821050755, 0.29400041480, 0.26497158886],
+])
+
+
+def nsinker_chi(x, n_sinkers, delta=200.0, omega=0.1):
+    """benchmarks/nsinker/nsinker.cc:61-76."""
+    chi = np.ones(x.shape[0])
+    for s in range(n_sinkers):
+        d = np.sqrt(((x - NSINKER_CENTERS[s][None, :]) ** 2).sum(axis=1))
+        t = np.maximum(0.0, d - omega / 2)
+        chi *= 1.0 - np.exp(-delta * t * t)
+    return chi
+
+
+@dataclass
+class StokesProblem:
+    name: str
+    dim: int
+    refinement: int
+    bc: list
+    eta: callable
+    force: callable                 # x -> rho*g vector [n, dim]
+    averaging: str
+    pressure_scaling: float
+    extents: list = None
+    reps: list = None
+    tol: float = 1e-7
+    restart: int = 100
+    n_cheap: int = 1000
+    n_expensive: int = 1000
+    krylov: str = "gmres"
+    idr_s: int = 2
+    initial_pressure: callable = None   # x -> p0 (unscaled), static pressure guess
+    hier: bm.BoxHierarchy = field(default=None, repr=False)
+
+    def build(self):
+        self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc)
+        self.eta_active, self.eta_levels, self.eta_min, self.eta_max = \
+            bm.viscosity_tables(self.hier, self.eta, self.averaging)
+        fin = self.hier.finest
+        self.rhs_u = bm.assemble_rhs_u(fin, self.force)
+        self.rhs_p = np.zeros(fin.n_dofs_p)
+        if self.initial_pressure is not None:
+            self.p0 = self.initial_pressure(fin.node_coords_p()) / self.pressure_scaling
+        else:
+            self.p0 = np.zeros(fin.n_dofs_p)
+        return self
+
+
+def nsinker_box(refinement, n_sinkers=8, ratio=1e6, averaging=bm.AVG_HARMONIC,
+                krylov="gmres", tol=1e-6, restart=100, n_cheap=200, n_expensive=0):
+    """benchmarks/nsinker/nsinker_gmg.prm + nsinker.cc (config 3)."""
+    sr = np.sqrt(ratio)
+
+    def eta(x):
+        chi = nsinker_chi(x, n_sinkers)
+        return (sr - 1.0 / sr) * (1.0 - chi) + 1.0 / sr
+
+    def force(x):
+        chi = nsinker_chi(x, n_sinkers)
+        f = np.zeros_like(x)
+        f[:, -1] = -1.0 * 10.0 * (1.0 - chi)     # gravity vertical magnitude 1, pointing down
+        return f
+
+    return StokesProblem(
+        name=f"nsinker_r{refinement}", dim=3, refinement=refinement,
+        bc=[bm.BC_ZERO] * 6, eta=eta, force=force, averaging=averaging,
+        pressure_scaling=1.0,                     # nsinker.cc:320-331 forces lambda = 1
+        tol=tol, restart=restart, n_cheap=n_cheap, n_expensive=n_expensive, krylov=krylov)
+
+
+def convection_box(dim, refinement):
+    """cookbooks/convection-box (2-D, config 1) / convection_box_3d (configs 2, 5)."""
+    if dim == 2:
+        g, alpha = 1e4, 1.0
+    else:
+        g, alpha = 1e16, 1e-10
+
+    def temperature(x):
+        z = x[:, -1]
+        t = (1 - z) - 0.01 * np.cos(np.pi * x[:, 0]) * np.sin(np.pi * z)
+        if dim == 3:
+            t = (1 - z) - 0.01 * np.cos(np.pi * x[:, 0]) * np.sin(np.pi * z) * x[:, 1] ** 3
+        return t
+
+    def force(x):
+        rho = 1.0 * (1.0 - alpha * temperature(x))
+        f = np.zeros_like(x)
+        f[:, -1] = -g * rho
+        return f
+
+    def p_static(x):
+        # adiabatic (reference-profile) pressure used as the first linearisation
+        # point: rho_ref * g * depth with the reference temperature T = 0
+        return 1.0 * g * (1.0 - x[:, -1])
+
+    return StokesProblem(
+        name=f"convection_box_{dim}d_r{refinement}", dim=dim, refinement=refinement,
+        bc=[bm.BC_TANGENTIAL] * (2 * dim), eta=lambda x: np.ones(x.shape[0]),
+        force=force, averaging=bm.AVG_PROJECT_Q1, pressure_scaling=100.0,
+        initial_pressure=p_static)
+
+
+def solcx(refinement, averaging=bm.AVG_HARMONIC, jump=1e6, n_cheap=1000):
+    """benchmarks/solcx: eta = 1 (x < 1/2) | jump, rho = -sin(pi z) cos(pi x)
+    (solcx.h:2969-2970, 3018); gravity vertical magnitude 1 default; free slip."""
+
+    def eta(x):
+        return np.where(x[:, 0] < 0.5, 1.0, jump)
+
+    def force(x):
+        rho = -np.sin(np.pi * x[:, 1]) * np.cos(np.pi * x[:, 0])
+        f = np.zeros_like(x)
+        f[:, 1] = -1.0 * rho
+        return f
+
+    # pressure scaling: exp(mean log eta)/L with L = 0.01 (helper_functions.cc:286-345)
+    lam = np.exp(0.5 * np.log(1.0) + 0.5 * np.log(jump)) / 0.01
+    return StokesProblem(
+        name=f"solcx_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_TANGENTIAL] * 4, eta=eta, force=force, averaging=averaging,
+        pressure_scaling=lam, n_cheap=n_cheap)
+
+
+def stokes_sinker_box(refinement):
+    """tests/stokes.prm: 3-D isoviscous box 2890 km, free slip, eta = 1e22,
+    rho = 3300 (+100 inside a sphere r = 200 km at the centre), g = 9.81."""
+    L = 2890000.0
+
+    def force(x):
+        r = np.sqrt(((x - 1445000.0) ** 2).sum(axis=1))
+        rho = 3300.0 + np.where(r > 200000.0, 0.0, 100.0)
+        f = np.zeros_like(x)
+        f[:, 2] = -9.81 * rho
+        return f
+
+    def p_static(x):
+        return 3300.0 * 9.81 * (L - x[:, 2])
+
+    return StokesProblem(
+        name=f"stokes_sinker_r{refinement}", dim=3, refinement=refinement,
+        bc=[bm.BC_TANGENTIAL] * 6, eta=lambda x: np.full(x.shape[0], 1e22),
+        force=force, averaging=bm.AVG_PROJECT_Q1, pressure_scaling=1e22 / (0.01 * L),
+        extents=[L, L, L], initial_pressure=p_static)

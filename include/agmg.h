@@ -1,0 +1,229 @@
+/* agmg.h -- C-ABI of the MI355X-native matrix-free block-GMG Stokes solve.
+ *
+ * Drop-in boundary for the hot path of tjhei/aspect (ASPECT 3.1.0-pre):
+ *   include/aspect/simulator/solver/matrix_free_operators.h:91-507
+ *       OperatorCellData, StokesOperator, BTBlockOperator, MassMatrixOperator,
+ *       ABlockOperator
+ *   include/aspect/simulator/solver/stokes_matrix_free.h:46-98, 113-354
+ *       StokesMatrixFreeHandler, BlockSchurGMGPreconditioner
+ *   source/simulator/solver/stokes_matrix_free_local_smoothing.cc:902-1544
+ *       StokesMatrixFreeHandlerLocalSmoothingImplementation::solve
+ *
+ * The reference has no FFI for this path: the boundary is C++ virtual dispatch
+ * plus deal.II's operator concept.  A thin C++ glue keeps those
+ * classes intact and forwards to the entry points below, flattening deal.II
+ * MatrixFree data into the tables declared here.
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no exception crosses the ABI.
+ *  - every int return is a status: 0 ok, 1 not converged, <0 error
+ *    (message via agmg_last_error()).
+ *  - one context per rank/GPU; calls are collective over the ranks of the
+ *    context; not thread-safe.
+ *  - host tables are copied during the call; the caller keeps ownership.
+ *  - velocity DoF numbering: dof = dim*node + component ("node-major"),
+ *    nodes being the Q2 support points in whatever (local) numbering the host
+ *    chooses; pressure DoF = Q1 node.  Cell-local node order is lexicographic
+ *    (x fastest), as in deal.II FEEvaluation.
+ *  - all arithmetic is FP64 (GMGNumberType = double, stokes_matrix_free.h:40).
+ */
+#ifndef AGMG_H
+#define AGMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agmg_ctx agmg_ctx;
+
+/* which operator, for agmg_vmult (matrix_free_operators.h:208-507) */
+enum { AGMG_OP_STOKES = 0, AGMG_OP_A = 1, AGMG_OP_BT = 2, AGMG_OP_MASS = 3 };
+/* geometry kinds: MappingCartesian (core.cc:118-119) vs MappingQ (core.cc:115-116) */
+enum { AGMG_GEOM_CARTESIAN = 0, AGMG_GEOM_GENERAL = 1 };
+/* Krylov method for the cheap phase (parameters.cc:466-482) */
+enum { AGMG_KRYLOV_GMRES = 0, AGMG_KRYLOV_IDR = 1 };
+/* level index of the active mesh in set_level/set_coefficients/vmult */
+#define AGMG_ACTIVE (-1)
+
+/* Solver parameters; mirrors "Solver parameters/Stokes solver parameters"
+ * (source/simulator/parameters.cc:432-584) and the constants hard-wired in
+ * local_smoothing.cc:918-969. */
+typedef struct agmg_options {
+  int32_t dim;                   /* 2 or 3 */
+  int32_t degree_v;              /* Stokes velocity polynomial degree; 2 supported */
+  int32_t device;                /* HIP device ordinal */
+  int32_t n_levels;              /* number of multigrid levels (n_global_levels) */
+  double  linear_tolerance;      /* Linear solver tolerance, default 1e-7 */
+  int32_t n_cheap_steps;         /* Number of cheap Stokes solver steps, default 1000 */
+  int32_t n_expensive_steps;     /* Maximum number of expensive Stokes solver steps, 1000 */
+  int32_t gmres_restart;         /* GMRES solver restart length, default 100 */
+  int32_t krylov_type;           /* AGMG_KRYLOV_* */
+  int32_t idr_s;                 /* IDR(s) parameter, default 2 */
+  double  A_block_tolerance;     /* Linear solver A block tolerance, 1e-2 */
+  double  S_block_tolerance;     /* Linear solver S block tolerance, 1e-6 */
+  int32_t A_block_is_symmetric;  /* sim.stokes_A_block_is_symmetric() */
+  int32_t coarse_on_host;        /* 1: level 0 smoother/solver runs on the host */
+  /* Chebyshev smoother constants, local_smoothing.cc:926-937, 947-948, 954-965 */
+  int32_t smoother_degree;       /* 4 */
+  double  smoothing_range;       /* 15 */
+  int32_t eig_cg_n_iterations;   /* 10 */
+  int32_t coarse_degree;         /* 8 */
+  double  coarse_range;          /* 1e-3 */
+  int32_t coarse_eig_cg_n_iterations; /* 100 */
+  int32_t schur_smoother_steps;  /* mg_smoother_Schur(4) */
+  /* multi-GPU: world size/rank of this context and an opaque 128-byte RCCL
+   * unique id shared by all ranks (ignored when world_size == 1) */
+  int32_t world_size;
+  int32_t rank;
+  uint8_t nccl_id[128];
+} agmg_options;
+
+void agmg_default_options(agmg_options *opt);
+
+/* One mesh level (an MG level 0..n_levels-1, or the active mesh AGMG_ACTIVE);
+ * what MatrixFree + MGConstrainedDoFs + MGTransferMF hold for it
+ * (local_smoothing.cc:1710-1877). */
+typedef struct agmg_level_desc {
+  int32_t n_cells;
+  int32_t n_nodes_v;              /* locally relevant Q2 nodes (owned first, then ghosts) */
+  int32_t n_nodes_p;              /* locally relevant Q1 nodes */
+  int32_t n_owned_nodes_v;        /* == n_nodes_v on one rank */
+  int32_t n_owned_nodes_p;
+  const uint32_t *cell_nodes_v;   /* [n_cells][3^dim] */
+  const uint32_t *cell_nodes_p;   /* [n_cells][2^dim] */
+  const uint8_t  *constrained_v;  /* [n_nodes_v] bit c: component c is a homogeneous Dirichlet row */
+  const uint8_t  *constrained_p;  /* [n_nodes_p] or NULL */
+  int32_t geometry_kind;          /* AGMG_GEOM_* */
+  const double *cell_h;           /* CARTESIAN: [n_cells][dim] cell extents */
+  const double *inv_jacobian;     /* GENERAL:   [n_cells][3^dim][dim][dim], (J^-1)_{ed} = d xi_e / d x_d */
+  const double *jxw;              /* GENERAL:   [n_cells][3^dim] */
+  /* transfer to the next coarser level (NULL on level 0 and on the active mesh):
+   * parent cell index on level-1 and child number (bit d: upper half in direction d) */
+  const int32_t *parent_cell;     /* [n_cells] */
+  const uint8_t *child_index;     /* [n_cells] */
+  /* ghost exchange plan (world_size > 1), per neighbour rank; nodes are local indices */
+  int32_t n_neighbors;
+  const int32_t *neighbor_rank;   /* [n_neighbors] */
+  const int32_t *send_offsets_v;  /* [n_neighbors+1] into send_nodes_v */
+  const uint32_t *send_nodes_v;   /* owned nodes whose values the neighbour ghosts */
+  const int32_t *recv_offsets_v;  /* [n_neighbors+1]; ghost node g of neighbour k lives at
+                                     local index n_owned_nodes_v + recv_offsets_v[k] + g */
+  const int32_t *send_offsets_p;
+  const uint32_t *send_nodes_p;
+  const int32_t *recv_offsets_p;
+} agmg_level_desc;
+
+/* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */
+typedef struct agmg_cell_data {
+  int32_t is_compressible;
+  int32_t enable_newton_derivatives;
+  int32_t enable_prescribed_dilation;
+  int32_t symmetrize_newton_system;
+  double  pressure_scaling;
+  int32_t n_q_viscosity;          /* second extent of the viscosity table: 1 or 3^dim */
+  const double *viscosity;        /* [n_cells][n_q_viscosity] */
+  /* Newton tables (active level only, local_smoothing.cc:447-663), or NULL */
+  const double *strain_rate_table;                 /* [n_cells][nq][dim(dim+1)/2] */
+  const double *newton_factor_wrt_strain_rate;     /* [n_cells][nq][dim(dim+1)/2] */
+  const double *newton_factor_wrt_pressure;        /* [n_cells][nq] */
+} agmg_cell_data;
+
+/* Mirrors the screen/statistics output of solve()
+ * (local_smoothing.cc:1421-1425, 1526-1536; SolverOutputs interface.h:36-58). */
+typedef struct agmg_solve_report {
+  int32_t n_cheap_iterations;
+  int32_t n_expensive_iterations;
+  int32_t n_A_preconditioner_cheap;      /* "A block preconditioner: a+b" */
+  int32_t n_A_preconditioner_expensive;
+  int32_t n_S_preconditioner_cheap;
+  int32_t n_S_preconditioner_expensive;
+  double  initial_nonlinear_residual;
+  double  final_linear_residual;
+  double  solver_tolerance;              /* absolute tolerance used */
+  double  solve_seconds;                 /* wall time of the on-device solve */
+  double  setup_seconds;                 /* smoother/eigenvalue setup inside solve() */
+  int32_t n_history;                     /* entries written to history */
+  double  history[2048];                 /* residual per outer iteration (cheap then expensive) */
+} agmg_solve_report;
+
+const char *agmg_last_error(void);
+
+/* create_matrix_free_solver + constructor (stokes_matrix_free.cc:29-62) */
+agmg_ctx *agmg_create(const agmg_options *opt);
+void      agmg_destroy(agmg_ctx *ctx);
+
+/* setup_dofs(): upload the tables of one level (local_smoothing.cc:1548-1878).
+ * level in [0, n_levels) or AGMG_ACTIVE. desc == NULL for AGMG_ACTIVE aliases
+ * the active mesh to the finest level (uniformly refined mesh, identical
+ * numbering). */
+int agmg_set_level(agmg_ctx *ctx, int level, const agmg_level_desc *desc);
+
+/* evaluate_material_model() -> OperatorCellData per level
+ * (local_smoothing.cc:172-445; set_cell_data matrix_free_operators.cc:151, 381, 511, 698) */
+int agmg_set_coefficients(agmg_ctx *ctx, int level, const agmg_cell_data *data);
+
+/* build_preconditioner(): ABlockOperator/MassMatrixOperator::compute_diagonal on
+ * every level (local_smoothing.cc:1882-1894; matrix_free_operators.cc:592-639, 799-829) */
+int agmg_compute_diagonals(agmg_ctx *ctx);
+
+/* {Stokes,ABlock,BTBlock,MassMatrix}Operator::vmult on host vectors
+ * (matrix_free_operators.cc:171-278, 399-432, 518-576, 760-783; wrapper
+ * semantics of deal.II MatrixFreeOperators::Base::vmult).
+ * STOKES/BT: src,dst = [n_dofs_v + n_dofs_p]; A: [n_dofs_v]; MASS: [n_dofs_p]. */
+int agmg_vmult(agmg_ctx *ctx, int which, int level, double *dst, const double *src);
+/* same on device pointers, asynchronous on the context's stream */
+int agmg_vmult_device(agmg_ctx *ctx, int which, int level, double *dst, const double *src);
+
+/* get_matrix_diagonal_inverse() of the level A / mass operators, copied to host */
+int agmg_get_inverse_diagonal(agmg_ctx *ctx, int which, int level, double *dst);
+
+/* MGTransferMF::prolongate_and_add / restrict_and_add for the velocity (which =
+ * AGMG_OP_A) or pressure (AGMG_OP_MASS) space, host vectors.
+ * prolongate: dst (level to_level) += P src (level to_level-1);
+ * restrict:   dst (level from_level-1) += P^T src (level from_level). */
+int agmg_prolongate_add(agmg_ctx *ctx, int which, int to_level, double *dst, const double *src);
+int agmg_restrict_add(agmg_ctx *ctx, int which, int from_level, double *dst, const double *src);
+
+/* Build the Chebyshev smoothers and estimate their eigenvalues on every level
+ * (local_smoothing.cc:918-993).  Called implicitly by agmg_solve; explicit for
+ * agmg_vcycle/agmg_precondition. */
+int agmg_setup_smoothers(agmg_ctx *ctx);
+/* eigenvalue estimates (max after the 1.2 safety factor, min as used) */
+int agmg_get_eigenvalue_estimates(agmg_ctx *ctx, int which, int level, double *lambda_min, double *lambda_max);
+
+/* PreconditionMG::vmult for the A block (AGMG_OP_A) or the Schur complement
+ * mass matrix (AGMG_OP_MASS): one V-cycle, active-mesh host vectors
+ * (local_smoothing.cc:1040-1058) */
+int agmg_vcycle(agmg_ctx *ctx, int which, double *dst, const double *src);
+
+/* BlockSchurGMGPreconditioner::vmult (stokes_matrix_free.h:237-354), host
+ * vectors [n_dofs_v + n_dofs_p]; expensive != 0 selects do_solve_A/do_solve_Schur */
+int agmg_precondition(agmg_ctx *ctx, int expensive, double *dst, const double *src);
+
+/* StokesMatrixFreeHandler::solve (local_smoothing.cc:902-1544), steps 1-7 of
+ * x holds the initial guess (velocity, scaled pressure) on entry
+ * and the solution on return; constrained entries of x are zeroed as
+ * current_constraints.set_zero does.  solve_newton_system selects the Newton
+ * tolerance branch (:1169-1183). */
+int agmg_solve(agmg_ctx *ctx, const double *rhs, double *x, int solve_newton_system,
+               agmg_solve_report *report);
+
+/* device-resident benchmark helpers: vectors live in the context
+ *   agmg_bench_vmult: n_repeat vmults of `which` on `level`, returns mean
+ *   seconds per vmult measured with HIP events on the context's stream
+ *   (the in-solver harness local_smoothing.cc:1234-1375). */
+int agmg_bench_vmult(agmg_ctx *ctx, int which, int level, int n_repeat, double *seconds_per_vmult);
+
+/* memory getters (stokes_matrix_free.h:75-98; postprocess/memory_statistics.cc:44-59) */
+size_t agmg_get_cell_data_memory_consumption(const agmg_ctx *ctx);
+size_t agmg_get_mg_transfer_memory_consumption(const agmg_ctx *ctx);
+size_t agmg_get_constraint_memory_consumption(const agmg_ctx *ctx);
+size_t agmg_get_dof_handler_memory_consumption(const agmg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGMG_H */
