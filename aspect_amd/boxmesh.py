@@ -171,13 +171,14 @@ class Level:
 class BoxHierarchy:
     """Levels 0..refinement of a box; level ``refinement`` is also the active mesh."""
 
-    def __init__(self, dim, refinement, extents=None, reps=None, bc=None):
+    def __init__(self, dim, refinement, extents=None, reps=None, bc=None, only_finest=False):
         self.dim = dim
         extents = [1.0] * dim if extents is None else extents
         reps = [1] * dim if reps is None else reps
         bc = [BC_TANGENTIAL] * (2 * dim) if bc is None else bc
         self.bc = list(bc)
-        self.levels = [Level(dim, extents, reps, l, bc) for l in range(refinement + 1)]
+        first = refinement if only_finest else 0
+        self.levels = [Level(dim, extents, reps, l, bc) for l in range(first, refinement + 1)]
 
     @property
     def finest(self):

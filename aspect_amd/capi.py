@@ -168,7 +168,7 @@ class Solver:
     equivalent of StokesMatrixFreeHandler's setup_dofs/assemble/
     build_preconditioner/solve sequence)."""
 
-    def __init__(self, lib: Library, problem, **opt_overrides):
+    def __init__(self, lib: Library, problem, single_level=False, **opt_overrides):
         self.lib = lib
         self.problem = problem
         hier = problem.hier
@@ -195,7 +195,8 @@ class Solver:
         for l, lev in enumerate(hier.levels):
             self._set_coeff(l, problem.eta_levels[l])
         self._set_coeff(ACTIVE, problem.eta_active)
-        self._check(lib.compute_diagonals(self.ctx))
+        if not single_level:
+            self._check(lib.compute_diagonals(self.ctx))
         fin = hier.finest
         self.n_u, self.n_p = fin.n_dofs_v, fin.n_dofs_p
 
@@ -221,7 +222,7 @@ class Solver:
         d.geometry_kind = GEOM_CARTESIAN
         d.cell_h = _ptr(ch, C.c_double)
         keep = [cnv, cnp, cmv, cmp_, ch]
-        if l > 0:
+        if l > 0 and lev.level > 0:
             nch = 1 << lev.dim
             par = (np.arange(lev.n_cells, dtype=np.int32) // nch).astype(np.int32)
             chi = (np.arange(lev.n_cells, dtype=np.int32) % nch).astype(np.uint8)

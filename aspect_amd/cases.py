@@ -71,6 +71,21 @@ class StokesProblem:
             self.p0 = np.zeros(fin.n_dofs_p)
         return self
 
+    def build_single_level(self):
+        """Only the active mesh (operator benchmarks on big levels: no hierarchy, no RHS)."""
+        self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
+                                    only_finest=True)
+        fin = self.hier.finest
+        nq = 3 ** self.dim
+        if self.averaging == bm.AVG_HARMONIC:
+            eta_q = self.eta(fin.qpoint_coords().reshape(-1, self.dim)).reshape(fin.n_cells, nq)
+            self.eta_active = (nq / np.sum(1.0 / eta_q, axis=1))[:, None]
+        else:
+            self.eta_active = self.eta(fin.qpoint_coords().reshape(-1, self.dim)).reshape(fin.n_cells, nq)
+        self.eta_levels = [self.eta_active]
+        self.eta_min, self.eta_max = float(self.eta_active.min()), float(self.eta_active.max())
+        return self
+
 
 def nsinker_box(refinement, n_sinkers=8, ratio=1e6, averaging=bm.AVG_HARMONIC,
                 krylov="gmres", tol=1e-6, restart=100, n_cheap=200, n_expensive=0):

@@ -1,0 +1,1496 @@
+// agmg.cpp -- host side of libaspect_amd.so: the C-ABI of include/agmg.h.
+//
+// Mirrors, for the hot path only, what the reference keeps in
+//   StokesMatrixFreeHandlerLocalSmoothingImplementation (setup_dofs / evaluate_material_model /
+//   build_preconditioner / solve, stokes_matrix_free_local_smoothing.cc:172-445, 902-1544, 1548-1894)
+//   BlockSchurGMGPreconditioner::vmult              (stokes_matrix_free.h:237-354)
+// and the deal.II pieces that path instantiates (PreconditionChebyshev, Multigrid::level_v_step,
+// mg::SmootherRelaxation, PreconditionMG, SolverGMRES/FGMRES/IDR/CG).
+// All vectors of the solve live in HBM; the host only sees scalars (dot products, Givens
+// rotations) and -- by default, as north_star asks -- the coarsest multigrid level.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <random>
+
+#include "agmg_internal.h"
+
+namespace agmg {
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+}  // namespace agmg
+
+using namespace agmg;
+
+#define CHECK(x)            \
+  do {                      \
+    const int rc_ = (x);    \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+namespace {
+
+inline int ipow(int b, int e) { int r = 1; while (e--) r *= b; return r; }
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct HostLevel {  // host copies kept for building the transfer tables
+  std::vector<uint32_t> cnv, cnp;
+  std::vector<int32_t> parent;
+  std::vector<uint8_t> child;
+};
+
+struct Smoother {  // PreconditionChebyshev state
+  double lmin = 0, lmax = 0, theta = 1, delta = 0;
+  int degree = 4;
+};
+
+struct CoarseOp {  // host-resident level 0: dense operator + Jacobi-Chebyshev "solver"
+  int n = 0;
+  std::vector<double> A, dinv;
+};
+
+// extreme eigenvalues of a symmetric tridiagonal matrix by Sturm-sequence bisection
+void tridiag_extreme_eigs(const std::vector<double> &d, const std::vector<double> &e, double &emin, double &emax) {
+  const int n = (int)d.size();
+  double lo = std::numeric_limits<double>::max(), hi = -lo;
+  for (int i = 0; i < n; ++i) {
+    const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0);
+    lo = std::min(lo, d[i] - r);
+    hi = std::max(hi, d[i] + r);
+  }
+  auto count_below = [&](double x) {  // number of eigenvalues < x
+    int cnt = 0;
+    double q = 1.0;
+    for (int i = 0; i < n; ++i) {
+      const double off2 = i > 0 ? e[i - 1] * e[i - 1] : 0.0;
+      q = (d[i] - x) - (i > 0 ? off2 / q : 0.0);
+      if (q == 0.0) q = 1e-300;
+      if (q < 0) ++cnt;
+    }
+    return cnt;
+  };
+  auto kth = [&](int k) {  // k-th smallest eigenvalue (0-based)
+    double a = lo, b = hi;
+    for (int it = 0; it < 200; ++it) {
+      const double m = 0.5 * (a + b);
+      if (m <= a || m >= b) break;
+      if (count_below(m) > k) b = m; else a = m;
+    }
+    return 0.5 * (a + b);
+  };
+  emin = kth(0);
+  emax = kth(n - 1);
+}
+
+// builds the CG tridiagonal incrementally (deal.II SolverCG eigenvalue signal)
+struct Lanczos {
+  std::vector<double> diag, off;
+  double alpha_old = 0;
+  void push(int it, double alpha, double beta) {
+    if (it == 1) diag.push_back(1.0 / alpha);
+    else { diag.push_back(1.0 / alpha + beta / alpha_old); off.push_back(std::sqrt(beta) / alpha_old); }
+    alpha_old = alpha;
+  }
+};
+
+void finish_smoother(Smoother &sm, const Lanczos &lz, double range) {
+  double emin = 1.0, emax = 1.0;
+  if (!lz.diag.empty()) {
+    double a, b;
+    tridiag_extreme_eigs(lz.diag, lz.off, a, b);
+    emin = a;
+    emax = 1.2 * b;
+  }
+  sm.lmax = emax;
+  const double alpha = range > 1.0 ? emax / range : std::min(0.9 * emax, emin);
+  sm.lmin = alpha;
+  sm.delta = 0.5 * (emax - alpha);
+  sm.theta = 0.5 * (emax + alpha);
+}
+
+enum { ST_SUCCESS = 0, ST_ITERATE = 1, ST_FAILURE = 2 };
+struct Control {  // deal.II SolverControl(max_steps, tol, log_history)
+  int max_steps;
+  double tol;
+  int last_step = 0;
+  double last_value = 0;
+  std::vector<double> history;
+  int check(int step, double v) {
+    last_step = step;
+    last_value = v;
+    history.push_back(v);
+    if (v <= tol) return ST_SUCCESS;
+    if (step >= max_steps || !std::isfinite(v)) return ST_FAILURE;
+    return ST_ITERATE;
+  }
+};
+
+}  // namespace
+
+struct agmg_ctx {
+  agmg_options opt;
+  hipStream_t stream = nullptr;
+  std::vector<DeviceLevel> L;
+  std::vector<HostLevel> H;
+  CoeffData active;
+  double *slots_u = nullptr, *slots_p = nullptr;
+  size_t slots_u_cap = 0, slots_p_cap = 0;
+  // multigrid work vectors, [0] = A block (velocity), [1] = Schur complement (pressure)
+  std::vector<double *> mg_def[2], mg_sol[2], mg_tmp[2], mg_t[2];
+  std::vector<Smoother> sm[2];
+  CoarseOp coarse[2];
+  bool mg_alloc = false, diag_ready = false, smoothers_ready = false;
+  double *dot_partials = nullptr, *dot_out_d = nullptr, *dot_out_h = nullptr;
+  std::vector<double *> pool;  // Krylov work vectors of size n_u + n_p
+  int nA = 0, nS = 0;          // V-cycle / inner iteration counters of the current preconditioner
+  std::vector<double> h0, h1;  // host staging for the coarse level
+
+  int nl() const { return (int)L.size(); }
+  DeviceLevel &fin() { return L.back(); }
+  const CoeffData &active_coeff() { return active.set ? active : fin().coeff; }
+  size_t size_of(int which, int l) const { return which == 0 ? (size_t)L[l].n_dofs_v() : (size_t)L[l].n_dofs_p(); }
+
+  template <class T> int dalloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    AGMG_HIP_CHECK(hipMalloc((void **)p, n * sizeof(T)));
+    return 0;
+  }
+  template <class T> void dfree(T *&p) {
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+  }
+  template <class T> int upload(T **p, const std::vector<T> &v) {
+    CHECK(dalloc(p, v.size()));
+    if (!v.empty()) AGMG_HIP_CHECK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int sync() { AGMG_HIP_CHECK(hipStreamSynchronize(stream)); return 0; }
+  int h2d(double *d, const double *h, size_t n) {
+    AGMG_HIP_CHECK(hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    return sync();
+  }
+  int d2h(double *h, const double *d, size_t n) {
+    AGMG_HIP_CHECK(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    return sync();
+  }
+
+  void free_level(DeviceLevel &l);
+  int ensure_workspace();
+  int ensure_transfers();
+  int ensure_mg_vectors();
+  int get_vec(size_t idx, double **p);
+
+  // out[k] = <x, ys[k]>, synchronous
+  int dots(const double *x, const std::vector<const double *> &ys, size_t n, double *out);
+  int norm(const double *x, size_t n, double *out) {
+    double v;
+    CHECK(dots(x, {x}, n, &v));
+    *out = std::sqrt(v);
+    return 0;
+  }
+
+  // level operators with fused epilogue: which 0 = A block, 1 = Schur mass matrix
+  int apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e);
+  int stokes_apply(const double *src, const EpiArgs &eu_in, double *dst);
+  int stokes_vmult(double *dst, const double *src);
+  int stokes_residual(double *dst, const double *rhs, const double *x);
+
+  int cheb_vmult(int which, int l, double *&x, double *&xo, const double *b);
+  int cheb_step(int which, int l, double *&x, double *&xo, const double *b);
+  int smoother_apply(int which, int l, const double *rhs);
+  int smoother_smooth(int which, int l, const double *rhs);
+  int coarse_solve(int which);
+  int level_v_step(int which, int l);
+  int vcycle(int which, double *dst, const double *src);
+  int estimate_device(int which, int l);
+  int build_coarse(int which);
+  int setup_smoothers();
+
+  int precondition(bool expensive, double *dst, const double *src, int *status);
+  int solver_cg(const std::function<int(double *, const double *)> &A,
+                const std::function<int(double *, const double *)> &P, double *x, const double *b, size_t n,
+                int max_it, double tol, double *work[4], int *its, bool *converged);
+};
+
+// ===================================================================== memory / setup
+void agmg_ctx::free_level(DeviceLevel &l) {
+  dfree(l.cnvT); dfree(l.cnpT); dfree(l.cmask_v); dfree(l.cmask_p); dfree(l.cell_hT); dfree(l.invJT); dfree(l.jxwT);
+  dfree(l.pull_ptr_v); dfree(l.pull_list_v); dfree(l.pull_ptr_p); dfree(l.pull_list_p);
+  dfree(l.coeff.etaT); dfree(l.inv_diag_A); dfree(l.inv_diag_M);
+  dfree(l.prol_parent_v); dfree(l.prol_pos_v); dfree(l.prol_parent_p); dfree(l.prol_pos_p);
+  dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
+  l = DeviceLevel();
+}
+
+int agmg_ctx::ensure_workspace() {
+  size_t nu = 0, np = 0;
+  const int dim = opt.dim, NV = ipow(3, dim), NP = ipow(2, dim);
+  for (auto &l : L) {
+    nu = std::max(nu, (size_t)NV * l.cstride * dim);
+    np = std::max(np, (size_t)NP * l.cstride * dim);
+  }
+  if (nu > slots_u_cap) { dfree(slots_u); CHECK(dalloc(&slots_u, nu)); slots_u_cap = nu; }
+  if (np > slots_p_cap) { dfree(slots_p); CHECK(dalloc(&slots_p, np)); slots_p_cap = np; }
+  if (!dot_partials) {
+    CHECK(dalloc(&dot_partials, (size_t)DOT_BLOCKS * DOT_MAX_VECS));
+    CHECK(dalloc(&dot_out_d, 256));
+    AGMG_HIP_CHECK(hipHostMalloc((void **)&dot_out_h, 256 * sizeof(double)));
+  }
+  return 0;
+}
+
+int agmg_ctx::ensure_mg_vectors() {
+  if (mg_alloc) return 0;
+  for (int w = 0; w < 2; ++w) {
+    for (auto *v : {&mg_def[w], &mg_sol[w], &mg_tmp[w], &mg_t[w]}) {
+      for (auto &p : *v) dfree(p);
+      v->assign(nl(), nullptr);
+    }
+    for (int l = 0; l < nl(); ++l) {
+      const size_t n = size_of(w, l);
+      CHECK(dalloc(&mg_def[w][l], n)); CHECK(dalloc(&mg_sol[w][l], n));
+      CHECK(dalloc(&mg_tmp[w][l], n)); CHECK(dalloc(&mg_t[w][l], n));
+    }
+    sm[w].assign(nl(), Smoother());
+  }
+  mg_alloc = true;
+  return 0;
+}
+
+int agmg_ctx::get_vec(size_t idx, double **p) {
+  const size_t n = (size_t)fin().n_dofs_v() + fin().n_dofs_p();
+  while (pool.size() <= idx) {
+    double *v;
+    CHECK(dalloc(&v, n));
+    pool.push_back(v);
+  }
+  *p = pool[idx];
+  return 0;
+}
+
+int agmg_ctx::dots(const double *x, const std::vector<const double *> &ys, size_t n, double *out) {
+  const int total = (int)ys.size();
+  if (total > 256) { set_error("dots: too many vectors"); return -1; }
+  for (int k0 = 0; k0 < total; k0 += DOT_MAX_VECS) {
+    const int nv = std::min(DOT_MAX_VECS, total - k0);
+    VecPtrs vp;
+    for (int k = 0; k < DOT_MAX_VECS; ++k) vp.p[k] = ys[k0 + std::min(k, nv - 1)];
+    CHECK(vec_multi_dot(stream, x, vp, nv, n, dot_partials, dot_out_d + k0));
+  }
+  AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+  CHECK(sync());
+  for (int k = 0; k < total; ++k) out[k] = dot_out_h[k];
+  return 0;
+}
+
+int agmg_ctx::ensure_transfers() {
+  const int dim = opt.dim, nch = 1 << dim;
+  for (int l = 1; l < nl(); ++l) {
+    DeviceLevel &F = L[l];
+    if (F.has_transfer) continue;
+    if (!F.set || !L[l - 1].set) { set_error("ensure_transfers: level not set"); return -1; }
+    const HostLevel &HF = H[l];
+    if (HF.parent.empty()) { set_error("level " + std::to_string(l) + " has no parent_cell/child_index table"); return -1; }
+    const DeviceLevel &C = L[l - 1];
+    std::vector<uint32_t> children((size_t)nch * C.cstride, 0xFFFFFFFFu);
+    for (int f = 0; f < F.n_cells; ++f) {
+      const int p = HF.parent[f], ch = HF.child[f];
+      if (p < 0 || p >= C.n_cells || ch >= nch) { set_error("bad parent_cell/child_index"); return -1; }
+      children[(size_t)ch * C.cstride + p] = f;
+    }
+    for (int p = 0; p < C.n_cells; ++p)
+      for (int ch = 0; ch < nch; ++ch)
+        if (children[(size_t)ch * C.cstride + p] == 0xFFFFFFFFu) { set_error("parent cell without 2^dim children (adaptive meshes: SURVEY.md 8f1)"); return -1; }
+    for (int p = C.n_cells; p < C.cstride; ++p)
+      for (int ch = 0; ch < nch; ++ch) children[(size_t)ch * C.cstride + p] = 0;
+    CHECK(upload(&F.childrenT, children));
+    F.bytes_transfer = children.size() * 4;
+    for (int vel = 0; vel < 2; ++vel) {
+      const int K = vel ? 2 : 1, n1 = K + 1, nf = 2 * K + 1, nloc = ipow(n1, dim);
+      const std::vector<uint32_t> &cn = vel ? HF.cnv : HF.cnp;
+      const int nn = vel ? F.n_nodes_v : F.n_nodes_p;
+      std::vector<uint32_t> par(nn, 0xFFFFFFFFu);
+      std::vector<uint8_t> pos(nn, 0);
+      std::vector<int> stamp(nn, -1);
+      std::vector<double> mult(nn, 0.0);
+      for (int p = 0; p < C.n_cells; ++p)
+        for (int ch = 0; ch < nch; ++ch) {
+          const uint32_t f = children[(size_t)ch * C.cstride + p];
+          for (int i = 0; i < nloc; ++i) {
+            int rem = i, pidx = 0, stride = 1;
+            for (int d = 0; d < dim; ++d) {
+              const int id = rem % n1;
+              rem /= n1;
+              pidx += (id + K * ((ch >> d) & 1)) * stride;
+              stride *= nf;
+            }
+            const uint32_t fn = cn[(size_t)f * nloc + i];
+            if (stamp[fn] != p) { stamp[fn] = p; mult[fn] += 1.0; }
+            if (par[fn] == 0xFFFFFFFFu) { par[fn] = p; pos[fn] = (uint8_t)pidx; }
+          }
+        }
+      for (int i = 0; i < nn; ++i) {
+        if (par[i] == 0xFFFFFFFFu) { par[i] = 0; mult[i] = 1.0; }  // node not touched by any cell
+        mult[i] = 1.0 / mult[i];
+      }
+      if (vel) { CHECK(upload(&F.prol_parent_v, par)); CHECK(upload(&F.prol_pos_v, pos)); CHECK(upload(&F.inv_mult_v, mult)); }
+      else { CHECK(upload(&F.prol_parent_p, par)); CHECK(upload(&F.prol_pos_p, pos)); CHECK(upload(&F.inv_mult_p, mult)); }
+      F.bytes_transfer += (size_t)nn * (4 + 1 + 8);
+    }
+    F.has_transfer = true;
+  }
+  return 0;
+}
+
+// ===================================================================== operators
+int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e) {
+  const DeviceLevel &lv = L[l];
+  if (which == 0) {
+    CHECK(launch_op_cells(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr));
+    return launch_pull_v(stream, lv, slots_u, e);
+  }
+  CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
+  return launch_pull_p(stream, lv, slots_p, 1, e);
+}
+
+// Stokes operator on the active mesh; epilogue kind/b taken from eu_in (STORE or RESID)
+int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst) {
+  const DeviceLevel &lv = fin();
+  const size_t nu = lv.n_dofs_v();
+  CHECK(launch_op_cells(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p));
+  EpiArgs eu = eu_in, ep = eu_in;
+  eu.dst = dst; eu.x = src;
+  ep.dst = dst + nu; ep.x = src + nu;
+  if (eu_in.b) ep.b = eu_in.b + nu;
+  CHECK(launch_pull_v(stream, lv, slots_u, eu));
+  return launch_pull_p(stream, lv, slots_p, lv.dim, ep);
+}
+int agmg_ctx::stokes_vmult(double *dst, const double *src) {
+  EpiArgs e;
+  e.epi = EPI_STORE;
+  return stokes_apply(src, e, dst);
+}
+int agmg_ctx::stokes_residual(double *dst, const double *rhs, const double *x) {
+  EpiArgs e;
+  e.epi = EPI_RESID;
+  e.b = rhs;
+  return stokes_apply(x, e, dst);
+}
+
+// ===================================================================== Chebyshev
+int agmg_ctx::cheb_vmult(int which, int l, double *&x, double *&xo, const double *b) {
+  const Smoother &s = sm[which][l];
+  const size_t n = size_of(which, l);
+  const double *dinv = which == 0 ? L[l].inv_diag_A : L[l].inv_diag_M;
+  CHECK(vec_pointwise_scale(stream, x, 1.0 / s.theta, dinv, b, n));
+  if (s.degree < 2 || std::fabs(s.delta) < 1e-40) return 0;
+  double rhok = s.delta / s.theta;
+  const double sigma = s.theta / s.delta;
+  for (int k = 0; k < s.degree - 1; ++k) {
+    const double rhokp = 1.0 / (2.0 * sigma - rhok);
+    EpiArgs e;
+    e.epi = EPI_CHEB; e.dst = xo; e.x = x; e.b = b; e.dinv = dinv;
+    e.xold = k == 0 ? nullptr : xo;
+    e.f1 = rhokp * rhok; e.f2 = 2.0 * rhokp / s.delta;
+    rhok = rhokp;
+    CHECK(apply_level(which, l, L[l].coeff, x, e));
+    std::swap(x, xo);
+  }
+  return 0;
+}
+int agmg_ctx::cheb_step(int which, int l, double *&x, double *&xo, const double *b) {
+  const Smoother &s = sm[which][l];
+  const double *dinv = which == 0 ? L[l].inv_diag_A : L[l].inv_diag_M;
+  {
+    EpiArgs e;
+    e.epi = EPI_CHEB; e.dst = xo; e.x = x; e.b = b; e.dinv = dinv; e.xold = nullptr; e.f1 = 0.0; e.f2 = 1.0 / s.theta;
+    CHECK(apply_level(which, l, L[l].coeff, x, e));
+    std::swap(x, xo);
+  }
+  if (s.degree < 2 || std::fabs(s.delta) < 1e-40) return 0;
+  double rhok = s.delta / s.theta;
+  const double sigma = s.theta / s.delta;
+  for (int k = 0; k < s.degree - 1; ++k) {
+    const double rhokp = 1.0 / (2.0 * sigma - rhok);
+    EpiArgs e;
+    e.epi = EPI_CHEB; e.dst = xo; e.x = x; e.b = b; e.dinv = dinv; e.xold = xo;
+    e.f1 = rhokp * rhok; e.f2 = 2.0 * rhokp / s.delta;
+    rhok = rhokp;
+    CHECK(apply_level(which, l, L[l].coeff, x, e));
+    std::swap(x, xo);
+  }
+  return 0;
+}
+
+// mg::SmootherRelaxation(steps): apply = vmult + (steps-1) step; smooth = steps x step
+int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
+  const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  CHECK(cheb_vmult(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
+  for (int i = 1; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
+  return 0;
+}
+int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
+  const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  for (int i = 0; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
+  return 0;
+}
+
+// level 0: MGCoarseGridApplySmoother = smoother apply (local_smoothing.cc:999-1004)
+int agmg_ctx::coarse_solve(int which) {
+  if (!opt.coarse_on_host) return smoother_apply(which, 0, mg_def[which][0]);
+  const CoarseOp &co = coarse[which];
+  const Smoother &s = sm[which][0];
+  const int n = co.n, steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  h0.resize(n);
+  CHECK(d2h(h0.data(), mg_def[which][0], n));
+  const std::vector<double> &b = h0;
+  std::vector<double> x(n), xo(n, 0.0), t(n);
+  auto matvec = [&](std::vector<double> &y, const std::vector<double> &v) {
+    for (int i = 0; i < n; ++i) {
+      double acc = 0;
+      const double *row = &co.A[(size_t)i * n];
+      for (int j = 0; j < n; ++j) acc += row[j] * v[j];
+      y[i] = acc;
+    }
+  };
+  auto update = [&](bool first, double f1, double f2) {
+    for (int i = 0; i < n; ++i) {
+      double v = (1.0 + f1) * x[i] + f2 * co.dinv[i] * (b[i] - t[i]);
+      if (!first) v -= f1 * xo[i];
+      xo[i] = v;
+    }
+    x.swap(xo);
+  };
+  auto recurrence = [&](bool zero_start) {
+    if (s.degree < 2 || std::fabs(s.delta) < 1e-40) return;
+    double rhok = s.delta / s.theta;
+    const double sigma = s.theta / s.delta;
+    for (int k = 0; k < s.degree - 1; ++k) {
+      matvec(t, x);
+      const double rhokp = 1.0 / (2.0 * sigma - rhok);
+      const double f1 = rhokp * rhok, f2 = 2.0 * rhokp / s.delta;
+      rhok = rhokp;
+      update(zero_start && k == 0, f1, f2);
+    }
+  };
+  for (int i = 0; i < n; ++i) x[i] = (1.0 / s.theta) * co.dinv[i] * b[i];
+  recurrence(true);
+  for (int st = 1; st < steps; ++st) {
+    matvec(t, x);
+    update(true, 0.0, 1.0 / s.theta);
+    recurrence(false);
+  }
+  return h2d(mg_sol[which][0], x.data(), n);
+}
+
+// Multigrid::level_v_step; uniformly refined meshes: no edge matrices
+int agmg_ctx::level_v_step(int which, int l) {
+  if (l == 0) return coarse_solve(which);
+  const DeviceLevel &F = L[l], &C = L[l - 1];
+  const bool vel = which == 0;
+  CHECK(smoother_apply(which, l, mg_def[which][l]));
+  {  // t = defect - A solution
+    EpiArgs e;
+    e.epi = EPI_RESID; e.dst = mg_t[which][l]; e.b = mg_def[which][l];
+    CHECK(apply_level(which, l, F.coeff, mg_sol[which][l], e));
+  }
+  {  // defect[l-1] = R t   (coarse Dirichlet rows dropped)
+    double *slots = vel ? slots_u : slots_p;
+    CHECK(launch_restrict_cells(stream, F, C, vel, mg_t[which][l], slots));
+    EpiArgs e;
+    e.epi = EPI_STORE; e.dst = mg_def[which][l - 1]; e.x = nullptr;
+    if (vel) CHECK(launch_pull_v(stream, C, slots, e));
+    else CHECK(launch_pull_p(stream, C, slots, 1, e));
+  }
+  CHECK(level_v_step(which, l - 1));
+  CHECK(launch_prolongate_add(stream, F, C, vel, mg_sol[which][l], mg_sol[which][l - 1]));
+  return smoother_smooth(which, l, mg_def[which][l]);
+}
+
+// PreconditionMG::vmult on device vectors of the active (= finest) mesh
+int agmg_ctx::vcycle(int which, double *dst, const double *src) {
+  const int top = nl() - 1;
+  double *saved = mg_def[which][top];
+  mg_def[which][top] = const_cast<double *>(src);  // read-only at the top level
+  const int rc = level_v_step(which, top);
+  mg_def[which][top] = saved;
+  CHECK(rc);
+  return vec_copy(stream, dst, mg_sol[which][top], size_of(which, top));
+}
+
+// eigenvalue estimate by eig_cg_n_iterations steps of Jacobi-preconditioned CG on the device
+int agmg_ctx::estimate_device(int which, int l) {
+  const size_t n = size_of(which, l);
+  const bool coarse_lvl = l == 0;
+  Smoother &s = sm[which][l];
+  s.degree = coarse_lvl ? opt.coarse_degree : opt.smoother_degree;
+  const double range = coarse_lvl ? opt.coarse_range : opt.smoothing_range;
+  const int max_it = coarse_lvl ? opt.coarse_eig_cg_n_iterations : opt.eig_cg_n_iterations;
+  const double *dinv = which == 0 ? L[l].inv_diag_A : L[l].inv_diag_M;
+  double *g = mg_def[which][l], *h = mg_sol[which][l], *d = mg_tmp[which][l], *Ad = mg_t[which][l];
+  // start vector: (index mod 11) minus its mean
+  CHECK(vec_fill_index_mod(stream, g, n, 11));
+  double sum = 0;
+  {
+    const size_t full = n / 11, rem = n % 11;
+    sum = (double)full * 55.0 + (double)(rem * (rem - 1) / 2);
+  }
+  CHECK(vec_shift(stream, g, -sum / (double)n, n));
+  Lanczos lz;
+  double res;
+  CHECK(norm(g, n, &res));
+  const double tol = 1e-10;
+  if (res > tol && max_it > 0) {
+    double gh = 0, alpha = 0, beta = 0;
+    for (int it = 1;; ++it) {
+      CHECK(vec_pointwise_scale(stream, h, 1.0, dinv, g, n));
+      const double gh_old = gh;
+      CHECK(dots(g, {h}, n, &gh));
+      if (it > 1) {
+        beta = gh / gh_old;
+        CHECK(vec_sadd(stream, d, beta, 1.0, h, n));
+      } else CHECK(vec_copy(stream, d, h, n));
+      EpiArgs e;
+      e.epi = EPI_STORE; e.dst = Ad; e.x = d;
+      CHECK(apply_level(which, l, L[l].coeff, d, e));
+      double dAd;
+      CHECK(dots(d, {Ad}, n, &dAd));
+      alpha = gh / dAd;
+      CHECK(vec_axpy(stream, g, -alpha, Ad, n));
+      CHECK(norm(g, n, &res));
+      lz.push(it, alpha, beta);
+      if (res <= tol || it >= max_it || !std::isfinite(res)) break;
+    }
+  }
+  finish_smoother(s, lz, range);
+  return 0;
+}
+
+// dense level-0 operator (by columns) + host eigenvalue estimate
+int agmg_ctx::build_coarse(int which) {
+  CoarseOp &co = coarse[which];
+  const int n = (int)size_of(which, 0);
+  co.n = n;
+  co.A.assign((size_t)n * n, 0.0);
+  co.dinv.resize(n);
+  double *x = mg_sol[which][0], *y = mg_t[which][0];
+  CHECK(vec_set(stream, x, 0.0, n));
+  std::vector<double> col(n);
+  const double one = 1.0, zero = 0.0;
+  for (int j = 0; j < n; ++j) {
+    AGMG_HIP_CHECK(hipMemcpyAsync(x + j, &one, sizeof(double), hipMemcpyHostToDevice, stream));
+    EpiArgs e;
+    e.epi = EPI_STORE; e.dst = y; e.x = x;
+    CHECK(apply_level(which, 0, L[0].coeff, x, e));
+    CHECK(d2h(col.data(), y, n));
+    AGMG_HIP_CHECK(hipMemcpyAsync(x + j, &zero, sizeof(double), hipMemcpyHostToDevice, stream));
+    for (int i = 0; i < n; ++i) co.A[(size_t)i * n + j] = col[i];
+  }
+  CHECK(d2h(co.dinv.data(), which == 0 ? L[0].inv_diag_A : L[0].inv_diag_M, n));
+  // host CG for the eigenvalue estimate
+  Smoother &s = sm[which][0];
+  s.degree = opt.coarse_degree;
+  std::vector<double> g(n), h(n), d(n), Ad(n);
+  double mean = 0;
+  for (int i = 0; i < n; ++i) { g[i] = (double)(i % 11); mean += g[i]; }
+  mean /= n;
+  for (auto &v : g) v -= mean;
+  auto dot = [&](const std::vector<double> &a, const std::vector<double> &b) {
+    double acc = 0;
+    for (int i = 0; i < n; ++i) acc += a[i] * b[i];
+    return acc;
+  };
+  Lanczos lz;
+  double res = std::sqrt(dot(g, g));
+  const double tol = 1e-10;
+  const int max_it = opt.coarse_eig_cg_n_iterations;
+  if (res > tol && max_it > 0) {
+    double gh = 0, alpha = 0, beta = 0;
+    for (int it = 1;; ++it) {
+      for (int i = 0; i < n; ++i) h[i] = co.dinv[i] * g[i];
+      const double gh_old = gh;
+      gh = dot(g, h);
+      if (it > 1) {
+        beta = gh / gh_old;
+        for (int i = 0; i < n; ++i) d[i] = h[i] + beta * d[i];
+      } else d = h;
+      for (int i = 0; i < n; ++i) {
+        double acc = 0;
+        for (int j = 0; j < n; ++j) acc += co.A[(size_t)i * n + j] * d[j];
+        Ad[i] = acc;
+      }
+      alpha = gh / dot(d, Ad);
+      for (int i = 0; i < n; ++i) g[i] -= alpha * Ad[i];
+      res = std::sqrt(dot(g, g));
+      lz.push(it, alpha, beta);
+      if (res <= tol || it >= max_it || !std::isfinite(res)) break;
+    }
+  }
+  finish_smoother(s, lz, opt.coarse_range);
+  return 0;
+}
+
+int agmg_ctx::setup_smoothers() {
+  if (!diag_ready) { set_error("setup_smoothers: call agmg_compute_diagonals first"); return -1; }
+  CHECK(ensure_workspace());
+  CHECK(ensure_transfers());
+  CHECK(ensure_mg_vectors());
+  for (int w = 0; w < 2; ++w)
+    for (int l = 0; l < nl(); ++l) {
+      if (l == 0 && opt.coarse_on_host) CHECK(build_coarse(w));
+      else CHECK(estimate_device(w, l));
+    }
+  smoothers_ready = true;
+  return 0;
+}
+
+// ===================================================================== block preconditioner
+// deal.II SolverCG on device vectors; work = {g, d, h, Ad}
+int agmg_ctx::solver_cg(const std::function<int(double *, const double *)> &A,
+                        const std::function<int(double *, const double *)> &P, double *x, const double *b, size_t n,
+                        int max_it, double tol, double *work[4], int *its, bool *converged) {
+  double *g = work[0], *d = work[1], *h = work[2], *Ad = work[3];
+  CHECK(A(g, x));
+  CHECK(vec_lincomb(stream, g, 1.0, b, -1.0, g, n));
+  double res;
+  CHECK(norm(g, n, &res));
+  *its = 0;
+  *converged = false;
+  if (res <= tol) { *converged = true; return 0; }
+  double gh = 0, alpha = 0, beta = 0;
+  for (int it = 1;; ++it) {
+    CHECK(P(h, g));
+    const double gh_old = gh;
+    CHECK(dots(g, {h}, n, &gh));
+    if (it > 1) {
+      beta = gh / gh_old;
+      CHECK(vec_sadd(stream, d, beta, 1.0, h, n));
+    } else CHECK(vec_copy(stream, d, h, n));
+    CHECK(A(Ad, d));
+    double dAd;
+    CHECK(dots(d, {Ad}, n, &dAd));
+    alpha = gh / dAd;
+    CHECK(vec_axpy(stream, x, alpha, d, n));
+    CHECK(vec_axpy(stream, g, -alpha, Ad, n));
+    CHECK(norm(g, n, &res));
+    *its = it;
+    if (res <= tol) { *converged = true; break; }
+    if (it >= max_it || !std::isfinite(res)) break;
+  }
+  return 0;
+}
+
+// BlockSchurGMGPreconditioner::vmult (stokes_matrix_free.h:237-354) on device block vectors
+int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *status) {
+  const DeviceLevel &lv = fin();
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
+  const int top = nl() - 1;
+  double *dst_u = dst, *dst_p = dst + nu;
+  const double *src_u = src, *src_p = src + nu;
+  double *utmp;
+  CHECK(get_vec(0, &utmp));
+  if (expensive) {
+    double nrm;
+    CHECK(norm(src_p, np, &nrm));
+    CHECK(vec_set(stream, dst_p, 0.0, np));
+    if (nrm > 1e-50) {
+      double *w0, *w1;
+      CHECK(get_vec(1, &w0)); CHECK(get_vec(2, &w1));
+      double *work[4] = {w0, w0 + np, w1, w1 + np};  // np <= nu: two pressure vectors fit one block vector
+      auto Aop = [&](double *d, const double *s) {
+        EpiArgs e; e.epi = EPI_STORE; e.dst = d; e.x = s;
+        return apply_level(1, top, active_coeff(), s, e);
+      };
+      auto Pop = [&](double *d, const double *s) { return vcycle(1, d, s); };
+      int its; bool conv;
+      CHECK(solver_cg(Aop, Pop, dst_p, src_p, np, 100, nrm * opt.S_block_tolerance, work, &its, &conv));
+      nS += its;
+      if (!conv && status) *status = -2;
+    }
+  } else {
+    CHECK(vcycle(1, dst_p, src_p));
+    nS += 1;
+  }
+  CHECK(vec_scale(stream, dst_p, -1.0, np));
+  {  // utmp = src_u - B^T dst_p
+    CHECK(launch_op_cells(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, dst_p, slots_u, nullptr));
+    EpiArgs e;
+    e.epi = EPI_RESID; e.dst = utmp; e.b = src_u; e.x = nullptr;
+    CHECK(launch_pull_v(stream, lv, slots_u, e));
+  }
+  if (expensive) {
+    double nrm;
+    CHECK(norm(utmp, nu, &nrm));
+    CHECK(vec_set(stream, dst_u, 0.0, nu));
+    double *w[4];
+    for (int i = 0; i < 4; ++i) CHECK(get_vec(1 + i, &w[i]));
+    auto Aop = [&](double *d, const double *s) {
+      EpiArgs e; e.epi = EPI_STORE; e.dst = d; e.x = s;
+      return apply_level(0, top, active_coeff(), s, e);
+    };
+    auto Pop = [&](double *d, const double *s) { return vcycle(0, d, s); };
+    int its; bool conv;
+    CHECK(solver_cg(Aop, Pop, dst_u, utmp, nu, 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
+    nA += its;
+    if (!conv && status) *status = -3;
+  } else {
+    CHECK(vcycle(0, dst_u, utmp));
+    nA += 1;
+  }
+  return 0;
+}
+
+// ===================================================================== Krylov solvers
+namespace {
+
+using Op = std::function<int(double *, const double *)>;
+
+struct Hessenberg {  // Givens-rotated least-squares state shared by GMRES and FGMRES
+  int m;
+  std::vector<double> gamma, ci, si;
+  std::vector<std::vector<double>> H;
+  explicit Hessenberg(int m_) : m(m_), gamma(m_ + 1, 0.0), ci(m_, 0.0), si(m_, 0.0), H(m_ + 1, std::vector<double>(m_, 0.0)) {}
+  double push(int j, std::vector<double> &h) {  // h has j+2 entries
+    for (int i = 0; i < j; ++i) {
+      const double t = h[i];
+      h[i] = ci[i] * t + si[i] * h[i + 1];
+      h[i + 1] = -si[i] * t + ci[i] * h[i + 1];
+    }
+    const double r = std::hypot(h[j], h[j + 1]);
+    ci[j] = h[j] / r;
+    si[j] = h[j + 1] / r;
+    h[j] = r;
+    gamma[j + 1] = -si[j] * gamma[j];
+    gamma[j] *= ci[j];
+    for (int i = 0; i <= j; ++i) H[i][j] = h[i];
+    return std::fabs(gamma[j + 1]);
+  }
+  std::vector<double> solve(int dim) const {
+    std::vector<double> y(dim);
+    for (int i = dim - 1; i >= 0; --i) {
+      double s = gamma[i];
+      for (int k = i + 1; k < dim; ++k) s -= H[i][k] * y[k];
+      y[i] = s / H[i][i];
+    }
+    return y;
+  }
+};
+
+// y += sum_i a[i] * xs[i]
+int multi_axpy(agmg_ctx *c, double *y, const std::vector<const double *> &xs, const std::vector<double> &a, size_t n) {
+  const int total = (int)xs.size();
+  for (int k0 = 0; k0 < total; k0 += DOT_MAX_VECS) {
+    const int nv = std::min(DOT_MAX_VECS, total - k0);
+    VecPtrs vp;
+    Coeffs co;
+    for (int k = 0; k < DOT_MAX_VECS; ++k) { vp.p[k] = xs[k0 + std::min(k, nv - 1)]; co.a[k] = k < nv ? a[k0 + k] : 0.0; }
+    CHECK(vec_multi_axpy(c->stream, y, vp, co, nv, n));
+  }
+  return 0;
+}
+
+// orthogonalise w against V[0..j] (classical Gram-Schmidt, fused dots, one re-orthogonalisation);
+// h[0..j] receives the coefficients, h[j+1] the norm of the remainder
+int orthogonalize(agmg_ctx *c, double *w, const std::vector<double *> &V, int j, size_t n, std::vector<double> &h) {
+  std::vector<const double *> vs(V.begin(), V.begin() + j + 1);
+  std::vector<double> hh(j + 1), neg(j + 1);
+  h.assign(j + 2, 0.0);
+  for (int pass = 0; pass < 2; ++pass) {
+    CHECK(c->dots(w, vs, n, hh.data()));
+    for (int i = 0; i <= j; ++i) { h[i] += hh[i]; neg[i] = -hh[i]; }
+    CHECK(multi_axpy(c, w, vs, neg, n));
+  }
+  double s;
+  CHECK(c->norm(w, n, &s));
+  h[j + 1] = s;
+  return 0;
+}
+
+// deal.II SolverGMRES, right preconditioning: x += P^-1 (V y) at convergence / restart
+int solver_gmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, size_t n, int restart,
+                 Control &ctl, size_t pool0, int *state_out) {
+  std::vector<double *> V;
+  double *p, *w;
+  CHECK(c->get_vec(pool0, &p));
+  CHECK(c->get_vec(pool0 + 1, &w));
+  auto basis = [&](int i, double **v) { return c->get_vec(pool0 + 2 + i, v); };
+  int acc = 0, state = ST_ITERATE;
+  do {
+    V.clear();
+    double *v0;
+    CHECK(basis(0, &v0));
+    CHECK(c->stokes_residual(v0, b, x));
+    double rho;
+    CHECK(c->norm(v0, n, &rho));
+    state = ctl.check(acc, rho);
+    if (state != ST_ITERATE) break;
+    CHECK(vec_scale(c->stream, v0, 1.0 / rho, n));
+    V.push_back(v0);
+    Hessenberg hs(restart);
+    hs.gamma[0] = rho;
+    int dim = 0;
+    for (int j = 0; j < restart && state == ST_ITERATE; ++j) {
+      ++acc;
+      CHECK(P(p, V[j]));
+      CHECK(A(w, p));
+      std::vector<double> h;
+      CHECK(orthogonalize(c, w, V, j, n, h));
+      double *vn;
+      CHECK(basis(j + 1, &vn));
+      const double s = h[j + 1];
+      CHECK(vec_lincomb(c->stream, vn, s != 0 ? 1.0 / s : 0.0, w, 0.0, w, n));
+      V.push_back(vn);
+      rho = hs.push(j, h);
+      dim = j + 1;
+      state = ctl.check(acc, rho);
+    }
+    const std::vector<double> y = hs.solve(dim);
+    CHECK(vec_set(c->stream, w, 0.0, n));
+    CHECK(multi_axpy(c, w, std::vector<const double *>(V.begin(), V.begin() + dim), y, n));
+    CHECK(P(p, w));
+    CHECK(vec_axpy(c->stream, x, 1.0, p, n));
+  } while (state == ST_ITERATE);
+  *state_out = state;
+  return 0;
+}
+
+// deal.II SolverFGMRES(max_basis_size)
+int solver_fgmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, size_t n, int basis_size,
+                  Control &ctl, size_t pool0, int *state_out) {
+  double *aux;
+  CHECK(c->get_vec(pool0, &aux));
+  auto vvec = [&](int i, double **v) { return c->get_vec(pool0 + 1 + 2 * i, v); };
+  auto zvec = [&](int i, double **v) { return c->get_vec(pool0 + 2 + 2 * i, v); };
+  int acc = 0, state = ST_ITERATE;
+  do {
+    CHECK(c->stokes_residual(aux, b, x));
+    double beta;
+    CHECK(c->norm(aux, n, &beta));
+    state = ctl.check(acc, beta);
+    if (state != ST_ITERATE) break;
+    std::vector<double *> V, Z;
+    Hessenberg hs(basis_size);
+    hs.gamma[0] = beta;
+    double *v;
+    CHECK(vvec(0, &v));
+    CHECK(vec_lincomb(c->stream, v, 1.0 / beta, aux, 0.0, aux, n));
+    int dim = 0;
+    for (int j = 0; j < basis_size && state == ST_ITERATE; ++j) {
+      V.push_back(v);
+      double *z;
+      CHECK(zvec(j, &z));
+      CHECK(P(z, V[j]));
+      Z.push_back(z);
+      CHECK(A(aux, z));
+      std::vector<double> h;
+      CHECK(orthogonalize(c, aux, V, j, n, h));
+      CHECK(vvec(j + 1, &v));
+      const double a = h[j + 1];
+      CHECK(vec_lincomb(c->stream, v, a != 0 ? 1.0 / a : 0.0, aux, 0.0, aux, n));
+      const double res = hs.push(j, h);
+      dim = j + 1;
+      state = ctl.check(++acc, res);
+    }
+    const std::vector<double> y = hs.solve(dim);
+    CHECK(multi_axpy(c, x, std::vector<const double *>(Z.begin(), Z.begin() + dim), y, n));
+  } while (state == ST_ITERATE);
+  *state_out = state;
+  return 0;
+}
+
+// deal.II SolverIDR(s), right preconditioned (van Gijzen & Sonneveld, bi-orthogonal variant)
+int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, size_t n, int s, Control &ctl,
+               size_t pool0, int *state_out) {
+  double *r, *v, *vhat, *uhat, *ghat;
+  size_t k0 = pool0;
+  CHECK(c->get_vec(k0++, &r)); CHECK(c->get_vec(k0++, &v)); CHECK(c->get_vec(k0++, &vhat));
+  CHECK(c->get_vec(k0++, &uhat)); CHECK(c->get_vec(k0++, &ghat));
+  std::vector<double *> G(s), U(s), Q(s);
+  for (int i = 0; i < s; ++i) { CHECK(c->get_vec(k0++, &G[i])); CHECK(c->get_vec(k0++, &U[i])); CHECK(c->get_vec(k0++, &Q[i])); }
+  hipStream_t st = c->stream;
+  CHECK(c->stokes_residual(r, b, x));
+  double res;
+  CHECK(c->norm(r, n, &res));
+  int step = 0;
+  int state = ctl.check(step, res);
+  *state_out = state;
+  if (state != ST_ITERATE) return 0;
+  std::vector<std::vector<double>> M(s, std::vector<double>(s, 0.0));
+  std::mt19937 rng(5489u);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> hq(n);
+  for (int i = 0; i < s; ++i) {
+    CHECK(vec_set(st, G[i], 0.0, n));
+    CHECK(vec_set(st, U[i], 0.0, n));
+    if (i != 0) {
+      for (auto &e : hq) e = nd(rng);
+      CHECK(c->h2d(Q[i], hq.data(), n));
+    } else CHECK(vec_copy(st, Q[i], r, n));
+    for (int j = 0; j < i; ++j) {
+      double d2[2];
+      CHECK(c->dots(Q[j], {Q[i], Q[j]}, n, d2));
+      CHECK(vec_axpy(st, Q[i], -d2[0] / d2[1], Q[j], n));
+    }
+    if (i != 0) {
+      double nn;
+      CHECK(c->norm(Q[i], n, &nn));
+      CHECK(vec_scale(st, Q[i], 1.0 / nn, n));
+    }
+    M[i][i] = 1.0;
+  }
+  double omega = 1.0;
+  bool early = false;
+  while (state == ST_ITERATE) {
+    ++step;
+    std::vector<double> phi(s);
+    CHECK(c->dots(r, std::vector<const double *>(Q.begin(), Q.end()), n, phi.data()));
+    for (int k = 0; k < s; ++k) {
+      std::vector<double> gamma(s - k);
+      for (int i = k; i < s; ++i) {
+        double sum = phi[i];
+        for (int j = k; j < i; ++j) sum -= M[i][j] * gamma[j - k];
+        gamma[i - k] = sum / M[i][i];
+      }
+      CHECK(vec_copy(st, v, r, n));
+      for (int i = k; i < s; ++i) CHECK(vec_axpy(st, v, -gamma[i - k], G[i], n));
+      CHECK(P(vhat, v));
+      CHECK(vec_lincomb(st, uhat, omega, vhat, 0.0, vhat, n));
+      for (int i = k; i < s; ++i) CHECK(vec_axpy(st, uhat, gamma[i - k], U[i], n));
+      CHECK(A(ghat, uhat));
+      if (k > 0) {
+        double dq;
+        CHECK(c->dots(Q[0], {ghat}, n, &dq));
+        double alpha = dq / M[0][0];
+        for (int i = 1; i < k; ++i) {
+          CHECK(vec_axpy(st, ghat, -alpha, G[i - 1], n));
+          CHECK(vec_axpy(st, uhat, -alpha, U[i - 1], n));
+          CHECK(c->dots(Q[i], {ghat}, n, &dq));
+          alpha = dq / M[i][i];
+        }
+        CHECK(vec_axpy(st, ghat, -alpha, G[k - 1], n));
+        CHECK(vec_axpy(st, uhat, -alpha, U[k - 1], n));
+      }
+      std::swap(G[k], ghat);
+      std::swap(U[k], uhat);
+      {
+        std::vector<double> col(s - k);
+        CHECK(c->dots(G[k], std::vector<const double *>(Q.begin() + k, Q.end()), n, col.data()));
+        for (int i = k; i < s; ++i) M[i][k] = col[i - k];
+      }
+      const double beta = phi[k] / M[k][k];
+      CHECK(vec_axpy(st, r, -beta, G[k], n));
+      CHECK(vec_axpy(st, x, beta, U[k], n));
+      CHECK(c->norm(r, n, &res));
+      state = ctl.check(step, res);
+      if (state != ST_ITERATE) { early = true; break; }
+      if (k + 1 < s) {
+        for (int i = 0; i < k + 1; ++i) phi[i] = 0.0;
+        for (int i = k + 1; i < s; ++i) phi[i] -= beta * M[i][k];
+      }
+    }
+    if (early) break;
+    CHECK(P(vhat, r));
+    CHECK(A(v, vhat));
+    double d2[2];
+    CHECK(c->dots(v, {r, v}, n, d2));
+    omega = d2[0] / d2[1];
+    CHECK(vec_axpy(st, r, -omega, v, n));
+    CHECK(vec_axpy(st, x, omega, vhat, n));
+    CHECK(c->norm(r, n, &res));
+    state = ctl.check(step, res);
+  }
+  *state_out = state;
+  return 0;
+}
+
+}  // namespace
+
+// ===================================================================== C API
+extern "C" {
+
+const char *agmg_last_error(void) { return agmg::g_error.c_str(); }
+
+void agmg_default_options(agmg_options *o) {
+  std::memset(o, 0, sizeof(*o));
+  o->dim = 3; o->degree_v = 2; o->device = 0; o->n_levels = 1;
+  o->linear_tolerance = 1e-7; o->n_cheap_steps = 1000; o->n_expensive_steps = 1000;
+  o->gmres_restart = 100; o->krylov_type = AGMG_KRYLOV_GMRES; o->idr_s = 2;
+  o->A_block_tolerance = 1e-2; o->S_block_tolerance = 1e-6; o->A_block_is_symmetric = 1;
+  o->coarse_on_host = 1;
+  o->smoother_degree = 4; o->smoothing_range = 15.0; o->eig_cg_n_iterations = 10;
+  o->coarse_degree = 8; o->coarse_range = 1e-3; o->coarse_eig_cg_n_iterations = 100;
+  o->schur_smoother_steps = 4;
+  o->world_size = 1; o->rank = 0;
+}
+
+agmg_ctx *agmg_create(const agmg_options *opt) {
+  if (!opt) { set_error("null options"); return nullptr; }
+  if (opt->dim != 2 && opt->dim != 3) { set_error("dim must be 2 or 3"); return nullptr; }
+  if (opt->degree_v != 2) { set_error("only Stokes velocity polynomial degree 2 (Q2-Q1) is built"); return nullptr; }
+  if (opt->n_levels < 1) { set_error("n_levels must be >= 1"); return nullptr; }
+  if (opt->world_size != 1) { set_error("world_size > 1: ghost exchange is not built yet (DESIGN.md, multi-GPU)"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: this library has no CPU path"); return nullptr; }
+  if (opt->device < 0 || opt->device >= ndev) { set_error("bad device ordinal"); return nullptr; }
+  if (hipSetDevice(opt->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+  auto *c = new agmg_ctx();
+  c->opt = *opt;
+  c->L.resize(opt->n_levels);
+  c->H.resize(opt->n_levels);
+  if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+  return c;
+}
+
+void agmg_destroy(agmg_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->opt.device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &l : c->L) c->free_level(l);
+  c->dfree(c->active.etaT);
+  c->dfree(c->slots_u); c->dfree(c->slots_p);
+  for (int w = 0; w < 2; ++w)
+    for (auto *v : {&c->mg_def[w], &c->mg_sol[w], &c->mg_tmp[w], &c->mg_t[w]})
+      for (auto &p : *v) c->dfree(p);
+  for (auto &p : c->pool) c->dfree(p);
+  c->dfree(c->dot_partials); c->dfree(c->dot_out_d);
+  if (c->dot_out_h) (void)hipHostFree(c->dot_out_h);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  if (level == AGMG_ACTIVE) {
+    if (d) { set_error("a separate active-mesh table is not supported: the active mesh must alias the finest level (uniformly refined meshes; adaptive = SURVEY.md 8f1)"); return -2; }
+    return 0;
+  }
+  if (level < 0 || level >= c->nl()) { set_error("bad level"); return -1; }
+  if (!d || d->n_cells <= 0 || !d->cell_nodes_v || !d->cell_nodes_p || !d->constrained_v) { set_error("incomplete level descriptor"); return -1; }
+  const int dim = c->opt.dim, NV = ipow(3, dim), NP = ipow(2, dim);
+  if ((unsigned)d->n_nodes_v > NODE_MASK || (unsigned)d->n_nodes_p > NODE_MASK) { set_error("too many nodes for 29-bit indices"); return -1; }
+  if (d->n_owned_nodes_v != d->n_nodes_v || d->n_owned_nodes_p != d->n_nodes_p || d->n_neighbors != 0) {
+    set_error("ghost nodes / neighbours given but world_size == 1");
+    return -1;
+  }
+  DeviceLevel &lv = c->L[level];
+  c->free_level(lv);
+  HostLevel &hl = c->H[level];
+  lv.dim = dim;
+  lv.n_cells = d->n_cells; lv.n_nodes_v = d->n_nodes_v; lv.n_nodes_p = d->n_nodes_p;
+  lv.cstride = (d->n_cells + 63) / 64 * 64;
+  const size_t cs = lv.cstride;
+  hl.cnv.assign(d->cell_nodes_v, d->cell_nodes_v + (size_t)lv.n_cells * NV);
+  hl.cnp.assign(d->cell_nodes_p, d->cell_nodes_p + (size_t)lv.n_cells * NP);
+  std::vector<uint8_t> cmv(d->constrained_v, d->constrained_v + lv.n_nodes_v);
+  std::vector<uint8_t> cmp(lv.n_nodes_p, 0);
+  if (d->constrained_p) cmp.assign(d->constrained_p, d->constrained_p + lv.n_nodes_p);
+  const uint8_t vmask = (uint8_t)((1u << dim) - 1u);
+  for (auto &m : cmv) m &= vmask;
+  for (auto &m : cmp) m &= 1u;
+  for (int vel = 0; vel < 2; ++vel) {
+    const int nloc = vel ? NV : NP, nn = vel ? lv.n_nodes_v : lv.n_nodes_p;
+    const std::vector<uint32_t> &cn = vel ? hl.cnv : hl.cnp;
+    const std::vector<uint8_t> &cm = vel ? cmv : cmp;
+    std::vector<uint32_t> T((size_t)nloc * cs);
+    std::vector<uint32_t> ptr((size_t)nn + 1, 0), list((size_t)lv.n_cells * nloc);
+    for (int cell = 0; cell < lv.n_cells; ++cell)
+      for (int a = 0; a < nloc; ++a) {
+        const uint32_t node = cn[(size_t)cell * nloc + a];
+        if ((int)node >= nn) { set_error(vel ? "cell_nodes_v out of range" : "cell_nodes_p out of range"); return -1; }
+        T[(size_t)a * cs + cell] = node | ((uint32_t)cm[node] << 29);
+        ++ptr[node + 1];
+      }
+    for (size_t cell = lv.n_cells; cell < cs; ++cell)
+      for (int a = 0; a < nloc; ++a) T[(size_t)a * cs + cell] = T[(size_t)a * cs + lv.n_cells - 1];
+    for (int i = 0; i < nn; ++i) ptr[i + 1] += ptr[i];
+    std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int cell = 0; cell < lv.n_cells; ++cell)
+      for (int a = 0; a < nloc; ++a) {
+        const uint32_t node = cn[(size_t)cell * nloc + a];
+        list[fill[node]++] = (uint32_t)((size_t)a * cs + cell);
+      }
+    if (vel) { CHECK(c->upload(&lv.cnvT, T)); CHECK(c->upload(&lv.pull_ptr_v, ptr)); CHECK(c->upload(&lv.pull_list_v, list)); CHECK(c->upload(&lv.cmask_v, cmv)); }
+    else { CHECK(c->upload(&lv.cnpT, T)); CHECK(c->upload(&lv.pull_ptr_p, ptr)); CHECK(c->upload(&lv.pull_list_p, list)); CHECK(c->upload(&lv.cmask_p, cmp)); }
+    lv.bytes_tables += (T.size() + ptr.size() + list.size()) * 4;
+    lv.bytes_constraints += cm.size();
+  }
+  lv.geom = d->geometry_kind;
+  const int NQ = NV;
+  if (lv.geom == AGMG_GEOM_CARTESIAN) {
+    if (!d->cell_h) { set_error("cell_h missing"); return -1; }
+    std::vector<double> hT((size_t)dim * cs, 1.0);
+    for (int cell = 0; cell < lv.n_cells; ++cell)
+      for (int k = 0; k < dim; ++k) {
+        const double h = d->cell_h[(size_t)cell * dim + k];
+        if (!(h > 0)) { set_error("cell_h must be positive"); return -1; }
+        hT[(size_t)k * cs + cell] = h;
+      }
+    CHECK(c->upload(&lv.cell_hT, hT));
+    lv.bytes_tables += hT.size() * 8;
+  } else if (lv.geom == AGMG_GEOM_GENERAL) {
+    if (!d->inv_jacobian || !d->jxw) { set_error("inv_jacobian / jxw missing"); return -1; }
+    const int dd = dim * dim;
+    std::vector<double> J((size_t)NQ * dd * cs, 0.0), W((size_t)NQ * cs, 1.0);
+    for (int cell = 0; cell < lv.n_cells; ++cell)
+      for (int q = 0; q < NQ; ++q) {
+        for (int e = 0; e < dd; ++e) J[((size_t)q * dd + e) * cs + cell] = d->inv_jacobian[((size_t)cell * NQ + q) * dd + e];
+        W[(size_t)q * cs + cell] = d->jxw[(size_t)cell * NQ + q];
+      }
+    CHECK(c->upload(&lv.invJT, J));
+    CHECK(c->upload(&lv.jxwT, W));
+    lv.bytes_tables += (J.size() + W.size()) * 8;
+  } else { set_error("bad geometry_kind"); return -1; }
+  hl.parent.clear(); hl.child.clear();
+  if (d->parent_cell && d->child_index) {
+    hl.parent.assign(d->parent_cell, d->parent_cell + lv.n_cells);
+    hl.child.assign(d->child_index, d->child_index + lv.n_cells);
+  }
+  CHECK(c->dalloc(&lv.inv_diag_A, (size_t)lv.n_dofs_v()));
+  CHECK(c->dalloc(&lv.inv_diag_M, (size_t)lv.n_dofs_p()));
+  lv.set = true;
+  if (level + 1 < c->nl()) c->L[level + 1].has_transfer = false;
+  c->mg_alloc = false; c->diag_ready = false; c->smoothers_ready = false;
+  for (auto &p : c->pool) c->dfree(p);
+  c->pool.clear();
+  return 0;
+}
+
+int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
+  if (!c || !d) { set_error("null argument"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  if (d->enable_newton_derivatives || d->enable_prescribed_dilation) {
+    set_error("Newton-derivative / prescribed-dilation terms are not built (SURVEY.md 8f3)");
+    return -2;
+  }
+  if (level != AGMG_ACTIVE && (level < 0 || level >= c->nl())) { set_error("bad level"); return -1; }
+  DeviceLevel &lv = level == AGMG_ACTIVE ? c->fin() : c->L[level];
+  if (!lv.set) { set_error("set_coefficients before set_level"); return -1; }
+  CoeffData &cd = level == AGMG_ACTIVE ? c->active : lv.coeff;
+  const int NQ = ipow(3, c->opt.dim);
+  if (d->n_q_viscosity != 1 && d->n_q_viscosity != NQ) { set_error("n_q_viscosity must be 1 or 3^dim"); return -1; }
+  if (!d->viscosity) { set_error("viscosity table missing"); return -1; }
+  const size_t cs = lv.cstride;
+  std::vector<double> T((size_t)d->n_q_viscosity * cs, 1.0);
+  for (int cell = 0; cell < lv.n_cells; ++cell)
+    for (int q = 0; q < d->n_q_viscosity; ++q) {
+      const double v = d->viscosity[(size_t)cell * d->n_q_viscosity + q];
+      if (!(v > 0)) { set_error("viscosity must be positive"); return -1; }
+      T[(size_t)q * cs + cell] = v;
+    }
+  c->dfree(cd.etaT);
+  CHECK(c->upload(&cd.etaT, T));
+  cd.nqv = d->n_q_viscosity;
+  cd.lambda = d->pressure_scaling;
+  cd.is_compressible = d->is_compressible;
+  cd.bytes = T.size() * 8;
+  cd.set = true;
+  c->diag_ready = false; c->smoothers_ready = false;
+  return 0;
+}
+
+int agmg_compute_diagonals(agmg_ctx *c) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  for (auto &l : c->L) if (!l.set || !l.coeff.set) { set_error("compute_diagonals: every level needs tables and coefficients"); return -1; }
+  CHECK(c->ensure_workspace());
+  for (auto &l : c->L) {
+    CHECK(launch_diag_cells(c->stream, l, l.coeff, c->slots_u, c->slots_p));
+    EpiArgs e;
+    e.epi = EPI_DIAG;
+    e.dst = l.inv_diag_A;
+    CHECK(launch_pull_v(c->stream, l, c->slots_u, e));
+    e.dst = l.inv_diag_M;
+    CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, e));
+  }
+  CHECK(c->sync());
+  c->diag_ready = true;
+  c->smoothers_ready = false;
+  return 0;
+}
+
+static int vmult_sizes(agmg_ctx *c, int which, int level, size_t *n) {
+  if (level != AGMG_ACTIVE && (level < 0 || level >= c->nl())) { set_error("bad level"); return -1; }
+  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->fin() : c->L[level];
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
+  switch (which) {
+    case AGMG_OP_STOKES: case AGMG_OP_BT: *n = nu + np; break;
+    case AGMG_OP_A: *n = nu; break;
+    case AGMG_OP_MASS: *n = np; break;
+    default: set_error("bad operator"); return -1;
+  }
+  return 0;
+}
+
+int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const double *src) {
+  if (!c) { set_error("null context"); return -1; }
+  size_t n;
+  CHECK(vmult_sizes(c, which, level, &n));
+  CHECK(c->ensure_workspace());
+  const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
+  const DeviceLevel &lv = c->L[l];
+  const CoeffData &cd = level == AGMG_ACTIVE ? c->active_coeff() : lv.coeff;
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
+  EpiArgs e;
+  e.epi = EPI_STORE; e.dst = dst; e.x = src;
+  switch (which) {
+    case AGMG_OP_A: return c->apply_level(0, l, cd, src, e);
+    case AGMG_OP_MASS: return c->apply_level(1, l, cd, src, e);
+    case AGMG_OP_STOKES: {
+      CHECK(launch_op_cells(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p));
+      CHECK(launch_pull_v(c->stream, lv, c->slots_u, e));
+      e.dst = dst + nu; e.x = src + nu;
+      return launch_pull_p(c->stream, lv, c->slots_p, lv.dim, e);
+    }
+    default: {  // B^T: both blocks of dst are written (vmult zeroes dst first)
+      CHECK(launch_op_cells(c->stream, lv, cd, AGMG_OP_BT, nullptr, src + nu, c->slots_u, nullptr));
+      CHECK(launch_pull_v(c->stream, lv, c->slots_u, e));
+      return vec_set(c->stream, dst + nu, 0.0, np);
+    }
+  }
+}
+
+int agmg_vmult(agmg_ctx *c, int which, int level, double *dst, const double *src) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  size_t n;
+  CHECK(vmult_sizes(c, which, level, &n));
+  double *ds, *dd;
+  CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
+  int rc = c->h2d(ds, src, n);
+  if (!rc) rc = agmg_vmult_device(c, which, level, dd, ds);
+  if (!rc) rc = c->d2h(dst, dd, n);
+  c->dfree(ds); c->dfree(dd);
+  return rc;
+}
+
+int agmg_get_inverse_diagonal(agmg_ctx *c, int which, int level, double *dst) {
+  if (!c || level < 0 || level >= c->nl()) { set_error("bad level"); return -1; }
+  if (!c->diag_ready) { set_error("diagonals not computed"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  const DeviceLevel &lv = c->L[level];
+  if (which == AGMG_OP_A) return c->d2h(dst, lv.inv_diag_A, lv.n_dofs_v());
+  if (which == AGMG_OP_MASS) return c->d2h(dst, lv.inv_diag_M, lv.n_dofs_p());
+  set_error("diagonal exists for A and MASS only (StokesOperator::compute_diagonal is ExcNotImplemented)");
+  return -1;
+}
+
+static int transfer_host(agmg_ctx *c, int which, int fine_level, bool prolong, double *dst, const double *src) {
+  if (!c || fine_level < 1 || fine_level >= c->nl()) { set_error("bad level for transfer"); return -1; }
+  if (which != AGMG_OP_A && which != AGMG_OP_MASS) { set_error("transfer: which must be A or MASS"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  CHECK(c->ensure_workspace());
+  CHECK(c->ensure_transfers());
+  const bool vel = which == AGMG_OP_A;
+  const DeviceLevel &F = c->L[fine_level], &C = c->L[fine_level - 1];
+  const size_t nf = vel ? F.n_dofs_v() : F.n_dofs_p(), ncz = vel ? C.n_dofs_v() : C.n_dofs_p();
+  const size_t nd = prolong ? nf : ncz, ns = prolong ? ncz : nf;
+  double *ds, *dd;
+  CHECK(c->dalloc(&ds, ns)); CHECK(c->dalloc(&dd, nd));
+  int rc = c->h2d(ds, src, ns);
+  if (!rc) rc = c->h2d(dd, dst, nd);
+  if (!rc) {
+    if (prolong) rc = launch_prolongate_add(c->stream, F, C, vel, dd, ds);
+    else {
+      double *slots = vel ? c->slots_u : c->slots_p;
+      rc = launch_restrict_cells(c->stream, F, C, vel, ds, slots);
+      EpiArgs e;
+      e.epi = EPI_ADD; e.dst = dd;
+      if (!rc) rc = vel ? launch_pull_v(c->stream, C, slots, e) : launch_pull_p(c->stream, C, slots, 1, e);
+    }
+  }
+  if (!rc) rc = c->d2h(dst, dd, nd);
+  c->dfree(ds); c->dfree(dd);
+  return rc;
+}
+int agmg_prolongate_add(agmg_ctx *c, int which, int to_level, double *dst, const double *src) {
+  return transfer_host(c, which, to_level, true, dst, src);
+}
+int agmg_restrict_add(agmg_ctx *c, int which, int from_level, double *dst, const double *src) {
+  return transfer_host(c, which, from_level, false, dst, src);
+}
+
+int agmg_setup_smoothers(agmg_ctx *c) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  return c->setup_smoothers();
+}
+
+int agmg_get_eigenvalue_estimates(agmg_ctx *c, int which, int level, double *lmin, double *lmax) {
+  if (!c || level < 0 || level >= c->nl() || !c->smoothers_ready) { set_error("smoothers not set up"); return -1; }
+  const Smoother &s = c->sm[which == AGMG_OP_A ? 0 : 1][level];
+  *lmin = s.lmin; *lmax = s.lmax;
+  return 0;
+}
+
+int agmg_vcycle(agmg_ctx *c, int which, double *dst, const double *src) {
+  if (!c) { set_error("null context"); return -1; }
+  if (which != AGMG_OP_A && which != AGMG_OP_MASS) { set_error("vcycle: which must be A or MASS"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  if (!c->smoothers_ready) CHECK(c->setup_smoothers());
+  const int w = which == AGMG_OP_A ? 0 : 1;
+  const size_t n = c->size_of(w, c->nl() - 1);
+  double *ds, *dd;
+  CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
+  int rc = c->h2d(ds, src, n);
+  if (!rc) rc = c->vcycle(w, dd, ds);
+  if (!rc) rc = c->d2h(dst, dd, n);
+  c->dfree(ds); c->dfree(dd);
+  return rc;
+}
+
+int agmg_precondition(agmg_ctx *c, int expensive, double *dst, const double *src) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  if (!c->smoothers_ready) CHECK(c->setup_smoothers());
+  const size_t n = (size_t)c->fin().n_dofs_v() + c->fin().n_dofs_p();
+  double *ds, *dd;
+  CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
+  int status = 0;
+  int rc = c->h2d(ds, src, n);
+  if (!rc) rc = c->precondition(expensive != 0, dd, ds, &status);
+  if (!rc) rc = c->d2h(dst, dd, n);
+  c->dfree(ds); c->dfree(dd);
+  if (!rc && status) { set_error("inner CG of the expensive preconditioner did not converge"); return 1; }
+  return rc;
+}
+
+int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_solve_report *rep) {
+  if (!c || !rhs_h || !x_h || !rep) { set_error("null argument"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  std::memset(rep, 0, sizeof(*rep));
+  rep->initial_nonlinear_residual = rep->final_linear_residual = std::numeric_limits<double>::quiet_NaN();
+  const double t_begin = now_s();
+  if (!c->smoothers_ready) CHECK(c->setup_smoothers());
+  CHECK(c->sync());
+  const double t_setup = now_s();
+  rep->setup_seconds = t_setup - t_begin;
+  const DeviceLevel &lv = c->fin();
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p(), n = nu + np;
+  hipStream_t st = c->stream;
+  // pool layout: 0..4 preconditioner scratch, 5 rhs, 6 x, 7 tmp, 8 x0, 9.. Krylov
+  double *rhs, *x, *tmp, *x0;
+  CHECK(c->get_vec(5, &rhs)); CHECK(c->get_vec(6, &x)); CHECK(c->get_vec(7, &tmp)); CHECK(c->get_vec(8, &x0));
+  CHECK(c->h2d(rhs, rhs_h, n));
+  CHECK(c->h2d(x, x_h, n));
+  // current_constraints.set_zero(initial guess), local_smoothing.cc:1116
+  CHECK(vec_zero_constrained(st, x, lv.cmask_v, lv.n_nodes_v, lv.dim));
+  double tol;
+  if (!newton) {  // local_smoothing.cc:1132-1167
+    CHECK(c->stokes_residual(tmp, rhs, x));
+    double r0;
+    CHECK(c->norm(tmp, n, &r0));
+    rep->initial_nonlinear_residual = r0;
+    CHECK(vec_copy(st, x0, x, n));
+    CHECK(vec_set(st, x0, 0.0, nu));
+    CHECK(c->stokes_residual(tmp, rhs, x0));
+    double d2[2];
+    CHECK(c->dots(tmp, {tmp}, nu, &d2[0]));
+    CHECK(c->dots(rhs + nu, {rhs + nu}, np, &d2[1]));
+    tol = c->opt.linear_tolerance * std::sqrt(d2[0] + d2[1]);
+  } else {  // :1169-1183
+    double r0;
+    CHECK(c->norm(rhs, n, &r0));
+    tol = c->opt.linear_tolerance * r0;
+    rep->initial_nonlinear_residual = r0;
+  }
+  rep->solver_tolerance = tol;
+  int inner_status = 0;
+  int nA_c = 0, nS_c = 0, nA_e = 0, nS_e = 0;
+  Op Aop = [&](double *d, const double *s) { return c->stokes_vmult(d, s); };
+  Op Pc = [&](double *d, const double *s) { return c->precondition(false, d, s, nullptr); };
+  Op Pe = [&](double *d, const double *s) { return c->precondition(true, d, s, &inner_status); };
+  Control cc{c->opt.n_cheap_steps, tol}, ce{c->opt.n_expensive_steps, tol};
+  int status = 0, state = ST_FAILURE;
+  const size_t pool0 = 9;
+  c->nA = c->nS = 0;
+  if (c->opt.n_cheap_steps > 0) {
+    if (c->opt.krylov_type == AGMG_KRYLOV_GMRES) CHECK(solver_gmres(c, Aop, Pc, x, rhs, n, c->opt.gmres_restart, cc, pool0, &state));
+    else CHECK(solver_idr(c, Aop, Pc, x, rhs, n, c->opt.idr_s, cc, pool0, &state));
+  }
+  nA_c = c->nA; nS_c = c->nS;
+  rep->n_cheap_iterations = cc.last_step;
+  rep->final_linear_residual = cc.last_value;
+  if (state != ST_SUCCESS) {
+    if (c->opt.n_expensive_steps == 0) status = 1;
+    else {
+      c->nA = c->nS = 0;
+      CHECK(solver_fgmres(c, Aop, Pe, x, rhs, n, c->opt.gmres_restart, ce, pool0, &state));
+      nA_e = c->nA; nS_e = c->nS;
+      rep->n_expensive_iterations = ce.last_step;
+      rep->final_linear_residual = ce.last_value;
+      if (state != ST_SUCCESS || inner_status) status = 1;
+    }
+  }
+  rep->n_A_preconditioner_cheap = nA_c; rep->n_S_preconditioner_cheap = nS_c;
+  rep->n_A_preconditioner_expensive = nA_e; rep->n_S_preconditioner_expensive = nS_e;
+  for (double v : cc.history) if (rep->n_history < 2048) rep->history[rep->n_history++] = v;
+  for (double v : ce.history) if (rep->n_history < 2048) rep->history[rep->n_history++] = v;
+  CHECK(c->d2h(x_h, x, n));
+  rep->solve_seconds = now_s() - t_setup;
+  if (status == 1) set_error("Stokes solver did not converge within the allowed steps");
+  return status;
+}
+
+int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *seconds_per_vmult) {
+  if (!c || n_repeat < 1 || !seconds_per_vmult) { set_error("bad argument"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  size_t n;
+  CHECK(vmult_sizes(c, which, level, &n));
+  const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
+  const DeviceLevel &lv = c->L[l];
+  double *src, *dst;
+  CHECK(c->dalloc(&src, n)); CHECK(c->dalloc(&dst, n));
+  {
+    std::vector<double> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = std::sin(0.37 * (double)i);
+    CHECK(c->h2d(src, h.data(), n));
+    if (which != AGMG_OP_MASS) CHECK(vec_zero_constrained(c->stream, src, lv.cmask_v, lv.n_nodes_v, lv.dim));
+  }
+  int rc = agmg_vmult_device(c, which, level, dst, src);  // warm-up
+  hipEvent_t e0, e1;
+  AGMG_HIP_CHECK(hipEventCreate(&e0));
+  AGMG_HIP_CHECK(hipEventCreate(&e1));
+  if (!rc) {
+    AGMG_HIP_CHECK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < n_repeat && !rc; ++i) rc = agmg_vmult_device(c, which, level, dst, src);
+    AGMG_HIP_CHECK(hipEventRecord(e1, c->stream));
+    AGMG_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    AGMG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *seconds_per_vmult = 1e-3 * (double)ms / n_repeat;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  c->dfree(src); c->dfree(dst);
+  return rc;
+}
+
+size_t agmg_get_cell_data_memory_consumption(const agmg_ctx *c) {
+  size_t s = c->active.bytes;
+  for (auto &l : c->L) s += l.coeff.bytes;
+  return s;
+}
+size_t agmg_get_mg_transfer_memory_consumption(const agmg_ctx *c) {
+  size_t s = 0;
+  for (auto &l : c->L) s += l.bytes_transfer;
+  return s;
+}
+size_t agmg_get_constraint_memory_consumption(const agmg_ctx *c) {
+  size_t s = 0;
+  for (auto &l : c->L) s += l.bytes_constraints;
+  return s;
+}
+size_t agmg_get_dof_handler_memory_consumption(const agmg_ctx *c) {
+  size_t s = 0;
+  for (auto &l : c->L) s += l.bytes_tables;
+  return s;
+}
+
+}  // extern "C"

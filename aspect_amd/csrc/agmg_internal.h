@@ -1,0 +1,137 @@
+// agmg_internal.h -- device-side data layout and kernel launch interfaces of
+// libaspect_amd.so (gfx950 only).  See DESIGN.md for the layout rationale.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/agmg.h"
+
+#define AGMG_HIP_CHECK(expr)                                                        \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      agmg::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));           \
+      return -100;                                                                  \
+    }                                                                               \
+  } while (0)
+
+namespace agmg {
+
+void set_error(const std::string &msg);
+
+constexpr uint32_t NODE_MASK = 0x1FFFFFFFu;  // low 29 bits: node index; high 3 bits: constraint bits
+constexpr int WAVES_PER_BLOCK = 4;
+// cell kernels: one lane per (cell, velocity component); 21 cells (3-D) or 32
+// cells (2-D) per 64-lane wavefront
+inline int cells_per_wave(int dim) { return 64 / dim; }
+
+// epilogues of the pull (node-owner) kernels
+enum Epilogue {
+  EPI_STORE = 0,    // dst = A x                        (constrained rows: x, or 0 if x == nullptr)
+  EPI_RESID = 1,    // dst = b - A x
+  EPI_CHEB = 2,     // dst = (1+f1) x - f1 xold + f2 dinv (b - A x)   (dst may alias xold)
+  EPI_ADD = 3,      // dst += sum  (constrained rows untouched)        [restriction]
+  EPI_DIAG = 4,     // dst = 1 / (constrained ? 1 : sum)               [inverse diagonal]
+  EPI_DIAG_RAW = 5  // dst = constrained ? 1 : sum
+};
+
+struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
+  bool set = false;
+  double *etaT = nullptr;  // [nqv][cstride]
+  int nqv = 0;
+  double lambda = 1.0;
+  int is_compressible = 0;
+  size_t bytes = 0;
+};
+
+struct DeviceLevel {
+  bool set = false;
+  int dim = 3;
+  int n_cells = 0, n_nodes_v = 0, n_nodes_p = 0;
+  int cstride = 0;                 // padded cell count (SoA row stride)
+  // SoA tables: [local index][cstride]
+  uint32_t *cnvT = nullptr;        // [3^dim][cstride]: node | cmask << 29
+  uint32_t *cnpT = nullptr;        // [2^dim][cstride]: node | cmask << 29
+  uint8_t *cmask_v = nullptr;      // [n_nodes_v]
+  uint8_t *cmask_p = nullptr;      // [n_nodes_p]
+  int geom = AGMG_GEOM_CARTESIAN;
+  double *cell_hT = nullptr;       // CARTESIAN [dim][cstride]
+  double *invJT = nullptr;         // GENERAL   [3^dim][dim*dim][cstride]
+  double *jxwT = nullptr;          // GENERAL   [3^dim][cstride]
+  // pull CSR (node -> contributing slots); entries a*cstride + cell
+  uint32_t *pull_ptr_v = nullptr;  // [n_nodes_v + 1]
+  uint32_t *pull_list_v = nullptr; // [n_cells * 3^dim]
+  uint32_t *pull_ptr_p = nullptr;
+  uint32_t *pull_list_p = nullptr; // [n_cells * 2^dim]
+  CoeffData coeff;
+  double *inv_diag_A = nullptr, *inv_diag_M = nullptr;
+  // transfer, stored on the FINE level: per fine node the parent cell (on
+  // level-1) and the position in the parent's (2k+1)^dim patch; per parent the
+  // child cells; 1/multiplicity of fine nodes over parent patches
+  uint32_t *prol_parent_v = nullptr; uint8_t *prol_pos_v = nullptr;
+  uint32_t *prol_parent_p = nullptr; uint8_t *prol_pos_p = nullptr;
+  double *inv_mult_v = nullptr, *inv_mult_p = nullptr;
+  uint32_t *childrenT = nullptr;   // [2^dim][cstride of level-1]: child cell ids on this level
+  bool has_transfer = false;
+  size_t bytes_tables = 0, bytes_transfer = 0, bytes_constraints = 0;
+  int n_dofs_v() const { return dim * n_nodes_v; }
+  int n_dofs_p() const { return n_nodes_p; }
+};
+
+struct EpiArgs {
+  int epi = EPI_STORE;
+  double *dst = nullptr;
+  const double *x = nullptr;     // the vector A was applied to (identity rows, Chebyshev)
+  const double *b = nullptr;
+  const double *xold = nullptr;
+  const double *dinv = nullptr;
+  double f1 = 0, f2 = 0;
+};
+
+// ---- operator launches (kernels_ops.hip) ----
+// cell kernels write per-cell contributions to `slots`; pull kernels sum them per DoF.
+// which: AGMG_OP_STOKES (reads u,p; writes slots_u, slots_p), AGMG_OP_A (u -> slots_u),
+// AGMG_OP_BT (p -> slots_u)
+int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which,
+                    const double *src_u, const double *src_p, double *slots_u, double *slots_p);
+int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p,
+                      double *slots_p);
+int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u,
+                      double *slots_p);
+int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e);
+// n_parts: partial values per (cell, i) slot (dim for the Stokes pressure rows, 1 for mass)
+int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e);
+
+// ---- transfer (kernels_transfer.hip) ----
+int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
+                          double *dst_fine, const double *src_coarse);
+// writes coarse-level slots; follow with launch_pull_{v,p}(coarse, slots, EPI_ADD)
+int launch_restrict_cells(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
+                          const double *src_fine, double *slots);
+
+// ---- vector kernels (kernels_vec.hip) ----
+int vec_set(hipStream_t s, double *x, double v, size_t n);
+int vec_copy(hipStream_t s, double *dst, const double *src, size_t n);
+int vec_scale(hipStream_t s, double *x, double a, size_t n);
+int vec_axpy(hipStream_t s, double *y, double a, const double *x, size_t n);              // y += a x
+int vec_sadd(hipStream_t s, double *y, double sy, double a, const double *x, size_t n);   // y = sy*y + a*x
+int vec_lincomb(hipStream_t s, double *dst, double a, const double *x, double b, const double *y, size_t n);
+int vec_pointwise_scale(hipStream_t s, double *dst, double f, const double *d, const double *b, size_t n);  // dst = f*d*b
+int vec_zero_constrained(hipStream_t s, double *x, const uint8_t *cmask, int n_nodes, int ncomp);
+int vec_fill_index_mod(hipStream_t s, double *x, size_t n, int mod);
+int vec_shift(hipStream_t s, double *x, double a, size_t n);  // x += a
+constexpr int DOT_BLOCKS = 256;
+constexpr int DOT_MAX_VECS = 8;
+// out[k] = <x, ys[k]> for k < nvec <= DOT_MAX_VECS; result on device in `out`
+// (workspace `partials` holds DOT_BLOCKS*DOT_MAX_VECS doubles)
+struct VecPtrs { const double *p[DOT_MAX_VECS]; };
+int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n,
+                  double *partials, double *out);
+struct Coeffs { double a[DOT_MAX_VECS]; };
+// y += sum_k a[k] * xs[k]
+int vec_multi_axpy(hipStream_t s, double *y, const VecPtrs &xs, const Coeffs &a, int nvec, size_t n);
+
+}  // namespace agmg

@@ -1,0 +1,610 @@
+// kernels_ops.hip -- Q2-Q1 sum-factorised cell kernels and node-owner pull kernels (gfx950).
+//
+// What these replace in the reference (tjhei/aspect 3.1.0-pre):
+//   k_cells<OP_A>       ABlockOperator::local_apply        matrix_free_operators.cc:705-783
+//   k_cells<OP_STOKES>  StokesOperator::local_apply        matrix_free_operators.cc:171-278
+//   k_cells<OP_BT>      BTBlockOperator::local_apply       matrix_free_operators.cc:399-432
+//   k_mass              MassMatrixOperator::local_apply    matrix_free_operators.cc:518-576
+//   k_diag_*            compute_diagonal                   matrix_free_operators.cc:592-639, 799-829
+//   k_pull              deal.II MatrixFreeOperators::Base::vmult wrapper (dst = 0, constrained rows
+//                       identity) fused with the Chebyshev / residual vector update
+//
+// Design: one lane per (cell, velocity component); 21 cells (3-D) or 32 cells (2-D)
+// per wavefront.  All 1-D contractions (3x3) run in registers; the only cross-lane step is the
+// transpose of the velocity gradient (sym grad needs du_d/dx_c from the lane of component d),
+// staged through a wave-private LDS tile, one quadrature plane at a time.  Scatter is atomic-free
+// and deterministic: every cell writes its contributions to a slot array laid out
+// [local dof][cell][component] (fully coalesced), and a node-owner pull kernel sums the slots of
+// each DoF in a fixed order and applies the vector epilogue.
+#include "agmg_internal.h"
+
+namespace agmg {
+
+namespace {
+
+constexpr double SQ06 = 0.774596669241483377035853079956;  // sqrt(3/5)
+constexpr double XQ0 = 0.5 - 0.5 * SQ06;
+// Q2 shape values at the first Gauss point (the third is the mirror image, the middle one is
+// the unit vector e_1 because the node 1/2 is a Gauss point)
+constexpr double N00 = (1 - XQ0) * (1 - 2 * XQ0), N01 = 4 * XQ0 * (1 - XQ0), N02 = XQ0 * (2 * XQ0 - 1);
+constexpr double M0 = 1 - XQ0, M1 = XQ0;  // Q1 shape values at the first Gauss point
+constexpr double INV_S = 1.0 / (0.5 * SQ06);  // 1 / spacing of the Gauss points
+constexpr double WQ0 = 5.0 / 18.0, WQ1 = 8.0 / 18.0;
+
+__host__ __device__ constexpr double wq1(int q) { return q == 1 ? WQ1 : WQ0; }
+__host__ __device__ constexpr double n1(int q, int i) {  // Q1 shape i at Gauss point q
+  return q == 1 ? 0.5 : ((q == 0) == (i == 0) ? M0 : M1);
+}
+__host__ __device__ constexpr double n2(int q, int i) {  // Q2 shape i at Gauss point q
+  return q == 1 ? (i == 1 ? 1.0 : 0.0) : (q == 0 ? (i == 0 ? N00 : (i == 1 ? N01 : N02))
+                                                 : (i == 0 ? N02 : (i == 1 ? N01 : N00)));
+}
+__host__ __device__ constexpr double d2(int q, int i) {  // Q2 shape derivative i at Gauss point q
+  const double x = q == 0 ? XQ0 : (q == 1 ? 0.5 : 1.0 - XQ0);
+  return i == 0 ? 4 * x - 3 : (i == 1 ? 4 - 8 * x : 4 * x - 1);
+}
+
+// ---- 1-D kernels on three values -------------------------------------------------------
+// nodal values -> values at the Gauss points (in place)
+__device__ __forceinline__ void interp3(double &a, double &b, double &c) {
+  const double t0 = fma(N00, a, fma(N01, b, N02 * c));
+  const double t2 = fma(N02, a, fma(N01, b, N00 * c));
+  a = t0;
+  c = t2;
+}
+// transpose of interp3 (in place)
+__device__ __forceinline__ void interp3T(double &a, double &b, double &c) {
+  const double o0 = fma(N00, a, N02 * c);
+  const double o1 = fma(N01, a + c, b);
+  const double o2 = fma(N02, a, N00 * c);
+  a = o0;
+  b = o1;
+  c = o2;
+}
+// collocation derivative at the (equispaced) Gauss points, times the spacing
+__device__ __forceinline__ void deriv3(double a, double b, double c, double &d0, double &d1, double &d2_) {
+  d0 = fma(-1.5, a, fma(2.0, b, -0.5 * c));
+  d1 = 0.5 * (c - a);
+  d2_ = fma(0.5, a, fma(-2.0, b, 1.5 * c));
+}
+// transpose of deriv3, accumulating
+__device__ __forceinline__ void deriv3T(double f0, double f1, double f2, double &ga, double &gb, double &gc) {
+  ga += fma(-1.5, f0, 0.5 * (f2 - f1));
+  gb += 2.0 * (f0 - f2);
+  gc += fma(1.5, f2, 0.5 * (f1 - f0));
+}
+__host__ __device__ constexpr double dcol(int q, int i) {  // collocation derivative matrix * spacing
+  return q == 0 ? (i == 0 ? -1.5 : (i == 1 ? 2.0 : -0.5))
+                : (q == 1 ? (i == 0 ? -0.5 : (i == 1 ? 0.0 : 0.5)) : (i == 0 ? 0.5 : (i == 1 ? -2.0 : 1.5)));
+}
+
+struct CellArgs {
+  int n_cells, cstride;
+  const uint32_t *cnvT, *cnpT;
+  const double *hT;
+  const double *etaT;
+  double lambda;
+  const double *src_u, *src_p;
+  double *slots_u, *slots_p;
+};
+
+enum { KOP_STOKES = 0, KOP_A = 1, KOP_BT = 2 };
+
+template <int DIM, int OP, bool COMP, bool PERQ>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArgs A) {
+  constexpr int NV = (DIM == 3) ? 27 : 9;
+  constexpr int NP = (DIM == 3) ? 8 : 4;
+  constexpr int NPL = NV / 3;   // points per plane (plane = last axis index fixed)
+  constexpr int NPLP = NP / 2;  // pressure nodes per plane
+  constexpr int CPW = 64 / DIM;
+  constexpr int LROW = 64 * DIM + 2;
+  constexpr bool HAS_U = (OP != KOP_BT);
+  constexpr bool HAS_P = (OP != KOP_A);
+  __shared__ double xbuf[HAS_U ? WAVES_PER_BLOCK : 1][HAS_U ? 3 : 1][HAS_U ? LROW : 1];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int j = lane / DIM;
+  const int c = lane - j * DIM;
+  const bool lane_ok = j < CPW;
+  if (!lane_ok) j = CPW - 1;
+  const long cell_l = ((long)blockIdx.x * WAVES_PER_BLOCK + wave) * CPW + j;
+  const bool valid = lane_ok && cell_l < A.n_cells;
+  const int cell = cell_l < A.n_cells ? (int)cell_l : A.n_cells - 1;
+  const size_t cs = (size_t)A.cstride;
+
+  // geometry (MappingCartesian): ih[d] = 1 / (spacing * h_d)
+  double ih[DIM], det = 1.0;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const double h = A.hT[d * cs + cell];
+    det *= h;
+    ih[d] = INV_S / h;
+  }
+  const double eta_c = PERQ ? 1.0 : A.etaT[cell];
+  double cw[DIM], lamc[DIM], ptc[DIM], compc[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    cw[d] = ih[d] * det * eta_c;
+    lamc[d] = (d == c) ? A.lambda * det * ih[d] : 0.0;
+    ptc[d] = (d == c) ? -0.5 * A.lambda * det : 0.0;
+    compc[d] = (d == c) ? (2.0 / 3.0) * cw[d] : 0.0;
+  }
+  (void)lamc; (void)ptc; (void)compc;
+
+  // gather (constrained DoFs read as zero)
+  double u[NV];
+  if (HAS_U) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      const uint32_t idx = A.cnvT[a * cs + cell];
+      const double v = A.src_u[(size_t)(idx & NODE_MASK) * DIM + c];
+      u[a] = ((idx >> (29 + c)) & 1u) ? 0.0 : v;
+    }
+    // nodal values -> values at the Gauss points, axis by axis
+#pragma unroll
+    for (int l = 0; l < NV / 3; ++l) interp3(u[3 * l], u[3 * l + 1], u[3 * l + 2]);
+#pragma unroll
+    for (int l = 0; l < NV / 3; ++l) {
+      const int b = (l % 3) + 9 * (l / 3);
+      interp3(u[b], u[b + 3], u[b + 6]);
+    }
+    if (DIM == 3) {
+#pragma unroll
+      for (int l = 0; l < 9; ++l) interp3(u[l], u[l + 9], u[l + 18]);
+    }
+  }
+  // pressure: nodal values -> per plane values along the last axis
+  double pz[3][NPLP];
+  if (HAS_P) {
+    double pin[NP];
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      const uint32_t idx = A.cnpT[b * cs + cell];
+      const double v = A.src_p[idx & NODE_MASK];
+      pin[b] = ((idx >> 29) & 1u) ? 0.0 : v;
+    }
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+#pragma unroll
+      for (int b = 0; b < NPLP; ++b) pz[z][b] = fma(n1(z, 0), pin[b], n1(z, 1) * pin[NPLP + b]);
+  }
+
+  double G[NV];
+#pragma unroll
+  for (int a = 0; a < NV; ++a) G[a] = 0.0;
+  double pout[NP];
+#pragma unroll
+  for (int b = 0; b < NP; ++b) pout[b] = 0.0;
+
+  // one batch = one line of three Gauss points along axis 0
+#pragma unroll
+  for (int L = 0; L < NV / 3; ++L) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int qy = (DIM == 3) ? L % 3 : L, qz = (DIM == 3) ? L / 3 : 0;
+    const int base = 3 * L;
+    double d[DIM][3];
+    double pq[3], pt[3];
+    if (HAS_P) {
+      // Q1 values on this line
+      double t0, t1;
+      if (DIM == 3) {
+        t0 = fma(n1(qy, 0), pz[qz][0], n1(qy, 1) * pz[qz][2]);
+        t1 = fma(n1(qy, 0), pz[qz][1], n1(qy, 1) * pz[qz][3]);
+      } else {
+        t0 = pz[qy][0];
+        t1 = pz[qy][1];
+      }
+#pragma unroll
+      for (int x = 0; x < 3; ++x) pq[x] = fma(n1(x, 0), t0, n1(x, 1) * t1);
+    }
+    if (HAS_U) {
+      // reference-space derivatives (times the Gauss point spacing)
+      deriv3(u[base], u[base + 1], u[base + 2], d[0][0], d[0][1], d[0][2]);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+          if (dcol(qy, m) != 0.0) s1 = fma(dcol(qy, m), u[9 * qz + 3 * m + x], s1);
+        d[1][x] = s1;
+        if (DIM == 3) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            if (dcol(qz, m) != 0.0) s2 = fma(dcol(qz, m), u[9 * m + 3 * qy + x], s2);
+          d[DIM - 1][x] = s2;
+        }
+      }
+      // physical gradient row of this lane's component -> LDS
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) {
+          d[dd][x] *= ih[dd];
+          xbuf[wave][x][lane * DIM + dd] = d[dd][x];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double wq = (DIM == 3) ? wq1(x) * wq1(qy) * wq1(qz) : wq1(x) * wq1(qy);
+      double f = wq;
+      if (PERQ) f *= A.etaT[(size_t)(base + x) * cs + cell];
+      if (HAS_U) {
+        // column c of the velocity gradient: du_dd/dx_c lives in the lane of component dd
+        double t[DIM];
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) t[dd] = d[dd][x] + xbuf[wave][x][(j * DIM + dd) * DIM + c];
+        double fdiv = 0.0;
+        if (COMP) {
+          double div = 0.0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) div += xbuf[wave][x][(j * DIM + e) * DIM + e];
+          fdiv = f * div;
+        }
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) {
+          double F = (cw[dd] * f) * t[dd];
+          if (COMP) F = fma(-compc[dd], fdiv, F);
+          if (HAS_P) F = fma(-lamc[dd], wq * pq[x], F);
+          d[dd][x] = F;
+        }
+        if (OP == KOP_STOKES) {
+          double s = 0.0;
+#pragma unroll
+          for (int dd = 0; dd < DIM; ++dd) s = fma(ptc[dd], t[dd], s);
+          pt[x] = wq * s;
+        }
+      } else {
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) d[dd][x] = -lamc[dd] * (wq * pq[x]);
+      }
+    }
+    if (HAS_U) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // transposed derivatives into G
+    deriv3T(d[0][0], d[0][1], d[0][2], G[base], G[base + 1], G[base + 2]);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+        if (dcol(qy, m) != 0.0) G[9 * qz + 3 * m + x] = fma(dcol(qy, m), d[1][x], G[9 * qz + 3 * m + x]);
+      if (DIM == 3) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+          if (dcol(qz, m) != 0.0) G[9 * m + 3 * qy + x] = fma(dcol(qz, m), d[DIM - 1][x], G[9 * m + 3 * qy + x]);
+      }
+    }
+    // pin the updated accumulators here: without this the compiler sinks the flux / G arithmetic
+    // of all lines below the LDS exchanges of all lines and spills the exchanged values
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      asm volatile("" : "+v"(G[base + x]) : : "memory");
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        if (m != qy && dcol(qy, m) != 0.0) asm volatile("" : "+v"(G[9 * qz + 3 * m + x]) : : "memory");
+        if (DIM == 3 && m != qz && dcol(qz, m) != 0.0) asm volatile("" : "+v"(G[9 * m + 3 * qy + x]) : : "memory");
+      }
+    }
+    if (OP == KOP_STOKES) {
+      // pressure test function: Gauss points of the line -> Q1 nodes
+      double r[2];
+#pragma unroll
+      for (int bx = 0; bx < 2; ++bx) r[bx] = fma(n1(0, bx), pt[0], fma(n1(1, bx), pt[1], n1(2, bx) * pt[2]));
+      if (DIM == 3) {
+#pragma unroll
+        for (int bz = 0; bz < 2; ++bz)
+#pragma unroll
+          for (int by = 0; by < 2; ++by)
+#pragma unroll
+            for (int bx = 0; bx < 2; ++bx)
+              pout[4 * bz + 2 * by + bx] = fma(n1(qz, bz) * n1(qy, by), r[bx], pout[4 * bz + 2 * by + bx]);
+      } else {
+#pragma unroll
+        for (int by = 0; by < 2; ++by)
+#pragma unroll
+          for (int bx = 0; bx < 2; ++bx) pout[2 * by + bx] = fma(n1(qy, by), r[bx], pout[2 * by + bx]);
+      }
+#pragma unroll
+      for (int b = 0; b < NP; ++b) asm volatile("" : "+v"(pout[b]) : : "memory");
+    }
+  }
+  // Gauss points -> nodes (transposed interpolation), axis by axis
+#pragma unroll
+  for (int l = 0; l < NV / 3; ++l) interp3T(G[3 * l], G[3 * l + 1], G[3 * l + 2]);
+#pragma unroll
+  for (int l = 0; l < NV / 3; ++l) {
+    const int b = (l % 3) + 9 * (l / 3);
+    interp3T(G[b], G[b + 3], G[b + 6]);
+  }
+  if (DIM == 3) {
+#pragma unroll
+    for (int l = 0; l < 9; ++l) interp3T(G[l], G[l + 9], G[l + 18]);
+  }
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) A.slots_u[((size_t)a * cs + cell) * DIM + c] = G[a];
+    if (OP == KOP_STOKES) {
+#pragma unroll
+      for (int b = 0; b < NP; ++b) A.slots_p[((size_t)b * cs + cell) * DIM + c] = pout[b];
+    }
+  }
+}
+
+// ---- pressure mass matrix: one lane per cell ---------------------------------------------
+template <int DIM, bool PERQ>
+__global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
+  constexpr int NP = (DIM == 3) ? 8 : 4;
+  constexpr int NQ = (DIM == 3) ? 27 : 9;
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= A.n_cells) return;
+  const size_t cs = (size_t)A.cstride;
+  double det = 1.0;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) det *= A.hT[d * cs + cell];
+  const double scale = A.lambda * A.lambda * det;
+  double pin[NP];
+#pragma unroll
+  for (int b = 0; b < NP; ++b) {
+    const uint32_t idx = A.cnpT[b * cs + cell];
+    const double v = A.src_p[idx & NODE_MASK];
+    pin[b] = ((idx >> 29) & 1u) ? 0.0 : v;
+  }
+  const double inv_eta_c = PERQ ? 1.0 : 1.0 / A.etaT[cell];
+  double pout[NP];
+#pragma unroll
+  for (int b = 0; b < NP; ++b) pout[b] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+    double v = 0.0;
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
+      v = fma(w, pin[b], v);
+    }
+    const double wq = wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
+    // per-lane division as in matrix_free_operators.cc:556-563
+    const double ie = PERQ ? 1.0 / A.etaT[(size_t)q * cs + cell] : inv_eta_c;
+    v *= wq * scale * ie;
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
+      pout[b] = fma(w, v, pout[b]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NP; ++b) A.slots_p[(size_t)b * cs + cell] = pout[b];
+}
+
+// ---- diagonals -------------------------------------------------------------------------
+// velocity: lane per (cell, local node); entry (a, c) = sum_q JxW eta (|grad phi|^2 + (d_c phi)^2
+//           [- 2/3 (d_c phi)^2 if compressible])
+template <int DIM>
+__global__ void __launch_bounds__(256) k_diag_v(const CellArgs A, int comp, int nqv) {
+  constexpr int NV = (DIM == 3) ? 27 : 9;
+  constexpr int NQ = NV;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cell = (int)(t / NV), a = (int)(t - (long)cell * NV);
+  if (cell >= A.n_cells) return;
+  const size_t cs = (size_t)A.cstride;
+  double h[3] = {1, 1, 1}, det = 1.0;
+  for (int d = 0; d < DIM; ++d) { h[d] = A.hT[d * cs + cell]; det *= h[d]; }
+  const int ai[3] = {a % 3, (a / 3) % 3, a / 9};
+  double acc[3] = {0, 0, 0};
+  for (int q = 0; q < NQ; ++q) {
+    const int qi[3] = {q % 3, (q / 3) % 3, q / 9};
+    double g[3] = {0, 0, 0}, wq = 1.0;
+    for (int e = 0; e < DIM; ++e) {
+      double v = 1.0;
+      for (int d = 0; d < DIM; ++d) v *= (d == e) ? d2(qi[d], ai[d]) : n2(qi[d], ai[d]);
+      g[e] = v / h[e];
+      wq *= wq1(qi[e]);
+    }
+    const double eta = A.etaT[(nqv == 1 ? 0 : (size_t)q * cs) + cell];
+    double n2g = 0.0;
+    for (int e = 0; e < DIM; ++e) n2g += g[e] * g[e];
+    for (int cc = 0; cc < DIM; ++cc) {
+      double v = n2g + g[cc] * g[cc];
+      if (comp) v -= (2.0 / 3.0) * g[cc] * g[cc];
+      acc[cc] += wq * det * eta * v;
+    }
+  }
+  for (int cc = 0; cc < DIM; ++cc) A.slots_u[((size_t)a * cs + cell) * DIM + cc] = acc[cc];
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) k_diag_p(const CellArgs A, int nqv) {
+  constexpr int NP = (DIM == 3) ? 8 : 4;
+  constexpr int NQ = (DIM == 3) ? 27 : 9;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cell = (int)(t / NP), b = (int)(t - (long)cell * NP);
+  if (cell >= A.n_cells) return;
+  const size_t cs = (size_t)A.cstride;
+  double det = 1.0;
+  for (int d = 0; d < DIM; ++d) det *= A.hT[d * cs + cell];
+  double acc = 0.0;
+  for (int q = 0; q < NQ; ++q) {
+    const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+    const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
+    const double wq = wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
+    const double eta = A.etaT[(nqv == 1 ? 0 : (size_t)q * cs) + cell];
+    acc += wq * det * A.lambda * A.lambda / eta * w * w;
+  }
+  A.slots_p[(size_t)b * cs + cell] = acc;
+}
+
+// ---- node-owner pull + vector epilogue -----------------------------------------------------
+struct PullArgs {
+  const uint32_t *ptr, *list;
+  const double *slots;
+  const uint8_t *cmask;
+  int n_nodes;
+  EpiArgs e;
+};
+
+// NC: components per node (one thread each); NPARTS: partial values per slot summed by the thread
+template <int NC, int NPARTS>
+__global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)P.n_nodes * NC) return;
+  const int node = (int)(t / NC), c = (int)(t - (long)node * NC);
+  const uint32_t s = P.ptr[node], en = P.ptr[node + 1];
+  double sum = 0.0;
+  for (uint32_t k = s; k < en; ++k) {
+    const size_t base = (size_t)P.list[k] * (NC * NPARTS) + c * NPARTS;
+#pragma unroll
+    for (int part = 0; part < NPARTS; ++part) sum += P.slots[base + part];
+  }
+  const bool con = P.cmask ? ((P.cmask[node] >> c) & 1u) : false;
+  const EpiArgs &e = P.e;
+  double out;
+  switch (e.epi) {
+    case EPI_STORE:
+      out = con ? (e.x ? e.x[t] : 0.0) : sum;
+      break;
+    case EPI_RESID:
+      out = e.b[t] - (con ? (e.x ? e.x[t] : 0.0) : sum);
+      break;
+    case EPI_CHEB: {
+      const double x = e.x[t];
+      const double Ax = con ? x : sum;
+      double v = fma(e.f2 * e.dinv[t], e.b[t] - Ax, (1.0 + e.f1) * x);
+      if (e.xold) v = fma(-e.f1, e.xold[t], v);
+      out = v;
+      break;
+    }
+    case EPI_ADD:
+      if (con) return;
+      out = e.dst[t] + sum;
+      break;
+    case EPI_DIAG:
+      out = 1.0 / (con ? 1.0 : sum);
+      break;
+    default:
+      out = con ? 1.0 : sum;
+      break;
+  }
+  e.dst[t] = out;
+}
+
+CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
+                   double *slp) {
+  CellArgs a;
+  a.n_cells = L.n_cells;
+  a.cstride = L.cstride;
+  a.cnvT = L.cnvT;
+  a.cnpT = L.cnpT;
+  a.hT = L.cell_hT;
+  a.etaT = cd.etaT;
+  a.lambda = cd.lambda;
+  a.src_u = su;
+  a.src_p = sp;
+  a.slots_u = slu;
+  a.slots_p = slp;
+  return a;
+}
+
+template <int DIM, int OP>
+void launch_cells_t(hipStream_t s, const CellArgs &a, bool comp, bool perq) {
+  const int cpb = (64 / DIM) * WAVES_PER_BLOCK;
+  const dim3 grid((a.n_cells + cpb - 1) / cpb), block(64 * WAVES_PER_BLOCK);
+  if (comp) {
+    if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_cells<DIM, OP, true, false>), grid, block, 0, s, a);
+  } else {
+    if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_cells<DIM, OP, false, false>), grid, block, 0, s, a);
+  }
+}
+
+}  // namespace
+
+int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
+                    const double *src_p, double *slots_u, double *slots_p) {
+  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
+  if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
+  if (L.n_cells <= 0) return 0;
+  const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
+  const bool perq = cd.nqv > 1;
+  // the compressible term only exists where the velocity is read (A, Stokes)
+  const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
+  if (L.dim == 3) {
+    if (which == AGMG_OP_A) launch_cells_t<3, KOP_A>(s, a, comp, perq);
+    else if (which == AGMG_OP_STOKES) launch_cells_t<3, KOP_STOKES>(s, a, comp, perq);
+    else launch_cells_t<3, KOP_BT>(s, a, false, false);
+  } else {
+    if (which == AGMG_OP_A) launch_cells_t<2, KOP_A>(s, a, comp, perq);
+    else if (which == AGMG_OP_STOKES) launch_cells_t<2, KOP_STOKES>(s, a, comp, perq);
+    else launch_cells_t<2, KOP_BT>(s, a, false, false);
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, double *slots_p) {
+  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
+  if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
+  if (L.n_cells <= 0) return 0;
+  const CellArgs a = make_args(L, cd, nullptr, src_p, nullptr, slots_p);
+  const dim3 grid((L.n_cells + 255) / 256), block(256);
+  const bool perq = cd.nqv > 1;
+  if (L.dim == 3) {
+    if (perq) hipLaunchKernelGGL((k_mass<3, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_mass<3, false>), grid, block, 0, s, a);
+  } else {
+    if (perq) hipLaunchKernelGGL((k_mass<2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_mass<2, false>), grid, block, 0, s, a);
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u, double *slots_p) {
+  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
+  if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
+  if (L.n_cells <= 0) return 0;
+  const CellArgs a = make_args(L, cd, nullptr, nullptr, slots_u, slots_p);
+  const int nv = L.dim == 3 ? 27 : 9, np = L.dim == 3 ? 8 : 4;
+  const dim3 block(256);
+  const dim3 gv((unsigned)(((long)L.n_cells * nv + 255) / 256)), gp((unsigned)(((long)L.n_cells * np + 255) / 256));
+  if (L.dim == 3) {
+    hipLaunchKernelGGL((k_diag_v<3>), gv, block, 0, s, a, cd.is_compressible, cd.nqv);
+    hipLaunchKernelGGL((k_diag_p<3>), gp, block, 0, s, a, cd.nqv);
+  } else {
+    hipLaunchKernelGGL((k_diag_v<2>), gv, block, 0, s, a, cd.is_compressible, cd.nqv);
+    hipLaunchKernelGGL((k_diag_p<2>), gp, block, 0, s, a, cd.nqv);
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e) {
+  PullArgs p{L.pull_ptr_v, L.pull_list_v, slots, L.cmask_v, L.n_nodes_v, e};
+  const long n = (long)L.n_nodes_v * L.dim;
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (L.dim == 3) hipLaunchKernelGGL((k_pull<3, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((k_pull<2, 1>), grid, block, 0, s, p);
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e) {
+  PullArgs p{L.pull_ptr_p, L.pull_list_p, slots, L.cmask_p, L.n_nodes_p, e};
+  const long n = L.n_nodes_p;
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (n_parts == 1) hipLaunchKernelGGL((k_pull<1, 1>), grid, block, 0, s, p);
+  else if (n_parts == 2) hipLaunchKernelGGL((k_pull<1, 2>), grid, block, 0, s, p);
+  else if (n_parts == 3) hipLaunchKernelGGL((k_pull<1, 3>), grid, block, 0, s, p);
+  else { set_error("bad n_parts"); return -1; }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace agmg

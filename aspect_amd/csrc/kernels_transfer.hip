@@ -1,0 +1,186 @@
+// kernels_transfer.hip -- matrix-free multigrid transfer for Q2^dim / Q1 on uniformly refined
+// parents (gfx950).  Replaces deal.II MGTransferMF::prolongate_and_add / restrict_and_add as
+// wired by stokes_matrix_free_local_smoothing.cc:1871-1877: 1-D embedding
+// rows at x = 0, 1/4, 1/2, 3/4, 1 (Q2) or 0, 1/2, 1 (Q1), tensor product per component,
+// coarse Dirichlet entries zeroed before prolongation and dropped after restriction.
+//
+// Prolongation is node-owner ("pull"): one thread per fine DoF interpolates from ONE parent
+// cell that contains the node (the FE space is conforming, so every parent gives the same
+// value).  Restriction is its exact transpose, organised per (parent cell, coarse local DoF);
+// each fine value is weighted by 1/multiplicity over the parent patches so that the sum over
+// parents counts it once; contributions go to the coarse level's slot array and are summed by
+// the same deterministic pull kernel as the operators (EPI_ADD).
+#include "agmg_internal.h"
+
+namespace agmg {
+namespace {
+
+// Q2 embedding rows P2[r][i] = phi_i(r/4); Q1 rows P1[r][i] = psi_i(r/2)
+__host__ __device__ constexpr double p2row(int r, int i) {
+  return r == 0 ? (i == 0 ? 1.0 : 0.0)
+       : r == 1 ? (i == 0 ? 0.375 : (i == 1 ? 0.75 : -0.125))
+       : r == 2 ? (i == 1 ? 1.0 : 0.0)
+       : r == 3 ? (i == 0 ? -0.125 : (i == 1 ? 0.75 : 0.375))
+                : (i == 2 ? 1.0 : 0.0);
+}
+__host__ __device__ constexpr double p1row(int r, int i) {
+  return r == 0 ? (i == 0 ? 1.0 : 0.0) : r == 1 ? 0.5 : (i == 1 ? 1.0 : 0.0);
+}
+template <int K> __device__ __forceinline__ double prow(int r, int i) {
+  if (K == 2) {
+    const double t[5][3] = {{1, 0, 0}, {0.375, 0.75, -0.125}, {0, 1, 0}, {-0.125, 0.75, 0.375}, {0, 0, 1}};
+    return t[r][i];
+  } else {
+    const double t[3][2] = {{1, 0}, {0.5, 0.5}, {0, 1}};
+    return t[r][i];
+  }
+}
+
+struct ProlArgs {
+  int n_fine_nodes;
+  const uint32_t *parent;   // [n_fine_nodes]
+  const uint8_t *pos;       // [n_fine_nodes] position in the parent's (2K+1)^DIM patch
+  const uint32_t *cnT;      // coarse [ (K+1)^DIM ][cstride_c]
+  int cstride_c;
+  const double *src;
+  double *dst;
+};
+
+// K: polynomial degree (2 velocity, 1 pressure); NC: components per node
+template <int DIM, int K, int NC>
+__global__ void __launch_bounds__(256) k_prolongate_add(const ProlArgs A) {
+  constexpr int N1 = K + 1, NF = 2 * K + 1;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)A.n_fine_nodes * NC) return;
+  const int node = (int)(t / NC), c = (int)(t - (long)node * NC);
+  const uint32_t par = A.parent[node];
+  int pos = A.pos[node];
+  int r[3] = {0, 0, 0};
+  for (int d = 0; d < DIM; ++d) { r[d] = pos % NF; pos /= NF; }
+  double val = 0.0;
+  for (int i2 = 0; i2 < (DIM == 3 ? N1 : 1); ++i2) {
+    const double w2 = (DIM == 3) ? prow<K>(r[2], i2) : 1.0;
+    if (w2 == 0.0) continue;
+    for (int i1 = 0; i1 < N1; ++i1) {
+      const double w1 = w2 * prow<K>(r[1], i1);
+      if (w1 == 0.0) continue;
+      for (int i0 = 0; i0 < N1; ++i0) {
+        const double w = w1 * prow<K>(r[0], i0);
+        if (w == 0.0) continue;
+        const int a = i0 + N1 * (i1 + N1 * i2);
+        const uint32_t idx = A.cnT[(size_t)a * A.cstride_c + par];
+        if ((idx >> (29 + c)) & 1u) continue;  // coarse Dirichlet value reads as zero
+        val = fma(w, A.src[(size_t)(idx & NODE_MASK) * NC + c], val);
+      }
+    }
+  }
+  A.dst[t] += val;
+}
+
+struct RestrArgs {
+  int n_coarse_cells, cstride_c, cstride_f;
+  const uint32_t *childrenT;  // [2^DIM][cstride_c]
+  const uint32_t *cnfT;       // fine [(K+1)^DIM][cstride_f]
+  const double *inv_mult;     // [n_fine_nodes]
+  const double *src;          // fine vector
+  double *slots;              // coarse slots [a][cstride_c][NC]
+};
+
+template <int DIM, int K, int NC>
+__global__ void __launch_bounds__(256) k_restrict_cells(const RestrArgs A) {
+  constexpr int N1 = K + 1, NLOC = (DIM == 3) ? N1 * N1 * N1 : N1 * N1;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)A.n_coarse_cells * NLOC) return;
+  // cell fastest so that index loads and slot stores coalesce
+  const int a = (int)(t / A.n_coarse_cells), cell = (int)(t - (long)a * A.n_coarse_cells);
+  int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
+  double acc[NC];
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  // patch rows with a non-zero weight for coarse index i (K = 2): i=0 -> {0,1,3}; 1 -> {1,2,3};
+  // 2 -> {1,3,4}; (K = 1): 0 -> {0,1}; 1 -> {1,2}.  Loop over all rows and skip zeros.
+  constexpr int NF = 2 * K + 1;
+  for (int r2 = 0; r2 < (DIM == 3 ? NF : 1); ++r2) {
+    const double w2 = (DIM == 3) ? prow<K>(r2, ai[2]) : 1.0;
+    if (w2 == 0.0) continue;
+    for (int r1 = 0; r1 < NF; ++r1) {
+      const double w1 = w2 * prow<K>(r1, ai[1]);
+      if (w1 == 0.0) continue;
+      for (int r0 = 0; r0 < NF; ++r0) {
+        const double w = w1 * prow<K>(r0, ai[0]);
+        if (w == 0.0) continue;
+        // fine node at patch position (r0, r1, r2): child = upper half where r > K
+        const int rr[3] = {r0, r1, r2};
+        int child = 0, loc = 0, stride = 1;
+        for (int d = 0; d < DIM; ++d) {
+          const int up = rr[d] > K ? 1 : 0;
+          child |= up << d;
+          loc += (rr[d] - K * up) * stride;
+          stride *= N1;
+        }
+        const uint32_t fcell = A.childrenT[(size_t)child * A.cstride_c + cell];
+        const uint32_t fn = A.cnfT[(size_t)loc * A.cstride_f + fcell] & NODE_MASK;
+        const double wm = w * A.inv_mult[fn];
+        for (int c = 0; c < NC; ++c) acc[c] = fma(wm, A.src[(size_t)fn * NC + c], acc[c]);
+      }
+    }
+  }
+  for (int c = 0; c < NC; ++c) A.slots[((size_t)a * A.cstride_c + cell) * NC + c] = acc[c];
+}
+
+}  // namespace
+
+int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
+                          double *dst_fine, const double *src_coarse) {
+  if (!fine.has_transfer) { set_error("transfer tables not built for this level"); return -5; }
+  ProlArgs a;
+  a.n_fine_nodes = velocity ? fine.n_nodes_v : fine.n_nodes_p;
+  a.parent = velocity ? fine.prol_parent_v : fine.prol_parent_p;
+  a.pos = velocity ? fine.prol_pos_v : fine.prol_pos_p;
+  a.cnT = velocity ? coarse.cnvT : coarse.cnpT;
+  a.cstride_c = coarse.cstride;
+  a.src = src_coarse;
+  a.dst = dst_fine;
+  const int nc = velocity ? fine.dim : 1;
+  const long n = (long)a.n_fine_nodes * nc;
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (fine.dim == 3) {
+    if (velocity) hipLaunchKernelGGL((k_prolongate_add<3, 2, 3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_prolongate_add<3, 1, 1>), grid, block, 0, s, a);
+  } else {
+    if (velocity) hipLaunchKernelGGL((k_prolongate_add<2, 2, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_prolongate_add<2, 1, 1>), grid, block, 0, s, a);
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_restrict_cells(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
+                          const double *src_fine, double *slots) {
+  if (!fine.has_transfer) { set_error("transfer tables not built for this level"); return -5; }
+  RestrArgs a;
+  a.n_coarse_cells = coarse.n_cells;
+  a.cstride_c = coarse.cstride;
+  a.cstride_f = fine.cstride;
+  a.childrenT = fine.childrenT;
+  a.cnfT = velocity ? fine.cnvT : fine.cnpT;
+  a.inv_mult = velocity ? fine.inv_mult_v : fine.inv_mult_p;
+  a.src = src_fine;
+  a.slots = slots;
+  const int k1 = velocity ? 3 : 2;
+  const int nloc = fine.dim == 3 ? k1 * k1 * k1 : k1 * k1;
+  const long n = (long)coarse.n_cells * nloc;
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (fine.dim == 3) {
+    if (velocity) hipLaunchKernelGGL((k_restrict_cells<3, 2, 3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_restrict_cells<3, 1, 1>), grid, block, 0, s, a);
+  } else {
+    if (velocity) hipLaunchKernelGGL((k_restrict_cells<2, 2, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_restrict_cells<2, 1, 1>), grid, block, 0, s, a);
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace agmg

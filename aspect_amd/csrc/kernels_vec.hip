@@ -1,0 +1,178 @@
+// kernels_vec.hip -- streaming vector kernels of the Krylov / smoother layer (gfx950).
+// Replace the deal.II LinearAlgebra::distributed::Vector operations used by SolverGMRES /
+// SolverFGMRES / SolverIDR / SolverCG / PreconditionChebyshev on this path.
+// All are HBM-bound: grid-stride, 16 B per lane per access where alignment allows, reductions
+// in a fixed order (per-block tree, then one block over the block partials) so results are
+// bitwise reproducible run to run.
+#include "agmg_internal.h"
+
+namespace agmg {
+namespace {
+
+constexpr int VB = 256;
+inline unsigned grid_for(size_t n) {
+  size_t g = (n + VB - 1) / VB;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+__global__ void __launch_bounds__(VB) k_set(double *x, double v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) x[i] = v;
+}
+__global__ void __launch_bounds__(VB) k_copy(double *d, const double *s, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) d[i] = s[i];
+}
+__global__ void __launch_bounds__(VB) k_scale(double *x, double a, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) x[i] *= a;
+}
+__global__ void __launch_bounds__(VB) k_axpy(double *y, double a, const double *x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) y[i] = fma(a, x[i], y[i]);
+}
+__global__ void __launch_bounds__(VB) k_sadd(double *y, double sy, double a, const double *x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) y[i] = fma(a, x[i], sy * y[i]);
+}
+__global__ void __launch_bounds__(VB) k_lincomb(double *d, double a, const double *x, double b, const double *y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) d[i] = fma(a, x[i], b * y[i]);
+}
+__global__ void __launch_bounds__(VB) k_pointwise(double *d, double f, const double *dg, const double *b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) d[i] = f * dg[i] * b[i];
+}
+__global__ void __launch_bounds__(VB) k_zero_constrained(double *x, const uint8_t *cmask, size_t n, int ncomp) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t node = i / ncomp;
+    const int c = (int)(i - node * ncomp);
+    if ((cmask[node] >> c) & 1u) x[i] = 0.0;
+  }
+}
+__global__ void __launch_bounds__(VB) k_shift(double *x, double a, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) x[i] += a;
+}
+__global__ void __launch_bounds__(VB) k_fill_mod(double *x, size_t n, int mod) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) x[i] = (double)(i % mod);
+}
+
+template <int NV>
+__global__ void __launch_bounds__(VB) k_multi_dot(const double *x, VecPtrs ys, size_t n, double *partials) {
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const double xv = x[i];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = fma(xv, ys.p[k][i], acc[k]);
+  }
+  __shared__ double red[NV][VB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double v = 0.0;
+    for (int w = 0; w < VB / 64; ++w) v += red[threadIdx.x][w];
+    partials[(size_t)threadIdx.x * DOT_BLOCKS + blockIdx.x] = v;
+  }
+}
+__global__ void __launch_bounds__(DOT_BLOCKS) k_dot_final(const double *partials, int nblocks, double *out) {
+  // one block; blockIdx.x = vector index
+  const int k = blockIdx.x;
+  double v = threadIdx.x < nblocks ? partials[(size_t)k * DOT_BLOCKS + threadIdx.x] : 0.0;
+  __shared__ double red[DOT_BLOCKS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < DOT_BLOCKS / 64; ++w) s += red[w];
+    out[k] = s;
+  }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(VB) k_multi_axpy(double *y, VecPtrs xs, Coeffs a, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    double v = y[i];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v = fma(a.a[k], xs.p[k][i], v);
+    y[i] = v;
+  }
+}
+
+}  // namespace
+
+#define LAUNCH_VEC(kern, n, ...)                                                        \
+  do {                                                                                  \
+    if ((n) == 0) return 0;                                                             \
+    hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(VB), 0, s, __VA_ARGS__);           \
+    AGMG_HIP_CHECK(hipGetLastError());                                                  \
+    return 0;                                                                           \
+  } while (0)
+
+int vec_set(hipStream_t s, double *x, double v, size_t n) { LAUNCH_VEC(k_set, n, x, v, n); }
+int vec_copy(hipStream_t s, double *d, const double *src, size_t n) { LAUNCH_VEC(k_copy, n, d, src, n); }
+int vec_scale(hipStream_t s, double *x, double a, size_t n) { LAUNCH_VEC(k_scale, n, x, a, n); }
+int vec_axpy(hipStream_t s, double *y, double a, const double *x, size_t n) { LAUNCH_VEC(k_axpy, n, y, a, x, n); }
+int vec_sadd(hipStream_t s, double *y, double sy, double a, const double *x, size_t n) {
+  LAUNCH_VEC(k_sadd, n, y, sy, a, x, n);
+}
+int vec_lincomb(hipStream_t s, double *d, double a, const double *x, double b, const double *y, size_t n) {
+  LAUNCH_VEC(k_lincomb, n, d, a, x, b, y, n);
+}
+int vec_pointwise_scale(hipStream_t s, double *d, double f, const double *dg, const double *b, size_t n) {
+  LAUNCH_VEC(k_pointwise, n, d, f, dg, b, n);
+}
+int vec_zero_constrained(hipStream_t s, double *x, const uint8_t *cmask, int n_nodes, int ncomp) {
+  const size_t n = (size_t)n_nodes * ncomp;
+  LAUNCH_VEC(k_zero_constrained, n, x, cmask, n, ncomp);
+}
+int vec_shift(hipStream_t s, double *x, double a, size_t n) { LAUNCH_VEC(k_shift, n, x, a, n); }
+int vec_fill_index_mod(hipStream_t s, double *x, size_t n, int mod) { LAUNCH_VEC(k_fill_mod, n, x, n, mod); }
+
+int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n, double *partials,
+                  double *out) {
+  if (nvec < 1 || nvec > DOT_MAX_VECS) { set_error("vec_multi_dot: bad nvec"); return -1; }
+  size_t g = (n + VB - 1) / VB;
+  if (g > DOT_BLOCKS) g = DOT_BLOCKS;
+  if (g < 1) g = 1;
+  const dim3 grid((unsigned)g), block(VB);
+  switch (nvec) {
+    case 1: hipLaunchKernelGGL((k_multi_dot<1>), grid, block, 0, s, x, ys, n, partials); break;
+    case 2: hipLaunchKernelGGL((k_multi_dot<2>), grid, block, 0, s, x, ys, n, partials); break;
+    case 3: hipLaunchKernelGGL((k_multi_dot<3>), grid, block, 0, s, x, ys, n, partials); break;
+    case 4: hipLaunchKernelGGL((k_multi_dot<4>), grid, block, 0, s, x, ys, n, partials); break;
+    case 5: hipLaunchKernelGGL((k_multi_dot<5>), grid, block, 0, s, x, ys, n, partials); break;
+    case 6: hipLaunchKernelGGL((k_multi_dot<6>), grid, block, 0, s, x, ys, n, partials); break;
+    case 7: hipLaunchKernelGGL((k_multi_dot<7>), grid, block, 0, s, x, ys, n, partials); break;
+    default: hipLaunchKernelGGL((k_multi_dot<8>), grid, block, 0, s, x, ys, n, partials); break;
+  }
+  hipLaunchKernelGGL(k_dot_final, dim3(nvec), dim3(DOT_BLOCKS), 0, s, partials, (int)g, out);
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int vec_multi_axpy(hipStream_t s, double *y, const VecPtrs &xs, const Coeffs &a, int nvec, size_t n) {
+  if (nvec < 1 || nvec > DOT_MAX_VECS) { set_error("vec_multi_axpy: bad nvec"); return -1; }
+  if (n == 0) return 0;
+  const dim3 grid(grid_for(n)), block(VB);
+  switch (nvec) {
+    case 1: hipLaunchKernelGGL((k_multi_axpy<1>), grid, block, 0, s, y, xs, a, n); break;
+    case 2: hipLaunchKernelGGL((k_multi_axpy<2>), grid, block, 0, s, y, xs, a, n); break;
+    case 3: hipLaunchKernelGGL((k_multi_axpy<3>), grid, block, 0, s, y, xs, a, n); break;
+    case 4: hipLaunchKernelGGL((k_multi_axpy<4>), grid, block, 0, s, y, xs, a, n); break;
+    case 5: hipLaunchKernelGGL((k_multi_axpy<5>), grid, block, 0, s, y, xs, a, n); break;
+    case 6: hipLaunchKernelGGL((k_multi_axpy<6>), grid, block, 0, s, y, xs, a, n); break;
+    case 7: hipLaunchKernelGGL((k_multi_axpy<7>), grid, block, 0, s, y, xs, a, n); break;
+    default: hipLaunchKernelGGL((k_multi_axpy<8>), grid, block, 0, s, y, xs, a, n); break;
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace agmg

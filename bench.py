@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: Stokes / A-block matvec GDoF/s and block-GMG
+Stokes-solve time (3-D Q2-Q1), beside the CPU oracle timed on the host cores.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one StokesOperator::vmult (matrix_free_operators.cc:171-278 + deal.II wrapper) on the
+workload's active mesh with all inputs resident in HBM.  value = (velocity + pressure DoFs of all
+ranks) / time per step.  N > 1: every rank owns one GPU and an identical subdomain-sized problem
+(weak scaling); ghost exchange between subdomains is not built yet, so ranks are
+independent replicas and the line says so in config.parallelism.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6     # vector FP64 (no MFMA: 3x3 contractions)
+
+
+def algorithmic_bytes_per_cell(nqv, stokes=False):
+    """SURVEY.md 8(d), FP64 + 32-bit indices, compulsory traffic with perfect reuse of shared
+    DoFs: vectors 16 B/velocity DoF x 24 DoF/cell = 384; node indices 27 x 4 = 108 (one index
+    serves the 3 interleaved components: this build's layout; the 81-index figure would be 324);
+    viscosity 8 (cell-constant) or 216 (per-q); Cartesian geometry 32.  Stokes adds 16 B x 1
+    pressure DoF + 8 x 4 B indices = 48."""
+    b = 384 + 108 + (8 if nqv == 1 else 216) + 32
+    return b + (48 if stokes else 0)
+
+
+A_FLOP_PER_CELL = 6800.0     # ~6.8 kflop/cell, Cartesian
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--refinement", type=int, default=5, help="configs[1]: convection_box_3d, global refinement 5")
+    ap.add_argument("--large-refinement", type=int, default=7,
+                    help="extra A-block roofline point on a level that fills the chip (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from aspect_amd import capi, cases
+    lib = capi.load()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------------------------------------------------------- workload (configs[1])
+    prob = cases.convection_box(3, args.refinement).build()
+    solver = capi.Solver(lib, prob, device=local_rank)
+    fin = prob.hier.finest
+    nu, npd = fin.n_dofs_v, fin.n_dofs_p
+    n = nu + npd
+    src_h = np.sin(0.37 * np.arange(n))
+    src_h[:nu][fin.constrained_dofs_v()] = 0.0
+    src = torch.from_numpy(src_h).to(dev)
+    dst = torch.empty_like(src)
+
+    def step():
+        rc = lib.vmult_device(solver.ctx, capi.OP_STOKES, capi.ACTIVE, dst.data_ptr(), src.data_ptr())
+        if rc:
+            raise RuntimeError(lib.last_error().decode())
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * n / (dt / args.steps) / 1e9
+
+    # ---------------------------------------------------------------- kernel-level numbers (HIP events
+    # on the library's stream, inside agmg_bench_vmult)
+    nqv = prob.eta_active.shape[1]
+    t_A = solver.bench_vmult(capi.OP_A, capi.ACTIVE, 100)
+    t_S = solver.bench_vmult(capi.OP_STOKES, capi.ACTIVE, 100)
+    bytes_A = fin.n_cells * algorithmic_bytes_per_cell(nqv)
+    roof = {"kernel": "A-block vmult = k_cells<A> + k_pull (ABlockOperator::vmult)", "bound": "hbm",
+            "achieved": bytes_A / t_A / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_A / t_A / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "us_per_launch": 1e6 * t_A, "gdofs": nu / t_A / 1e9,
+            "fp64_frac": fin.n_cells * A_FLOP_PER_CELL / t_A / 1e12 / FP64_PEAK_TFLOPS,
+            "bytes_per_cell": algorithmic_bytes_per_cell(nqv)}
+
+    # ---------------------------------------------------------------- full solve
+    x, rep, rc = solver.solve(allow_failure=True)      # first call includes smoother setup
+    x, rep2, rc = solver.solve(allow_failure=True)
+    solve_s = max_over_ranks(rep2.solve_seconds)
+    extra = {"stokes_vmult_us": 1e6 * t_S, "a_block_vmult_us": 1e6 * t_A,
+             "a_block_gdofs": nu / t_A / 1e9,
+             "solve_seconds": solve_s, "solve_setup_seconds": rep.setup_seconds,
+             "gmres_iterations": f"{rep2.n_cheap_iterations}+{rep2.n_expensive_iterations}",
+             "vcycles_A": rep2.n_A_preconditioner_cheap, "vcycles_S": rep2.n_S_preconditioner_cheap,
+             "solve_status": rc, "velocity_dofs": nu, "pressure_dofs": npd}
+    solver.close()
+
+    # ---------------------------------------------------------------- chip-filling level
+    roof_large = None
+    if args.large_refinement and rank == 0:
+        pl = cases.convection_box(3, args.large_refinement)
+        pl.build_single_level()
+        sl = capi.Solver(lib, pl, device=local_rank, single_level=True)
+        fl = pl.hier.finest
+        tl = sl.bench_vmult(capi.OP_A, capi.ACTIVE, 20)
+        bl = fl.n_cells * algorithmic_bytes_per_cell(pl.eta_active.shape[1])
+        roof_large = {"workload": f"convection_box_3d r{args.large_refinement} ({fl.n_cells} cells, {fl.n_dofs_v} velocity DoFs)",
+                      "achieved": bl / tl / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": bl / tl / 1e9 / HBM_PEAK_GBS, "us_per_launch": 1e6 * tl,
+                      "gdofs": fl.n_dofs_v / tl / 1e9,
+                      "fp64_frac": fl.n_cells * A_FLOP_PER_CELL / tl / 1e12 / FP64_PEAK_TFLOPS}
+        sl.close()
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import pyoracle
+        o = pyoracle.solver(prob)
+        o.vmult(capi.OP_STOKES, src_h)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0 or reps < 3:
+            o.vmult(capi.OP_STOKES, src_h)
+            reps += 1
+        tc = (time.perf_counter() - t0) / reps
+        cpu = {"value": n / tc / 1e9, "unit": "GDoF/s", "cores": 1, "kind": "port",
+               "sample": f"{reps} Stokes vmults of the same r{args.refinement} workload by oracle/oracle.cpp (scalar C++, 1 thread)"}
+        o.close()
+
+    if rank == 0:
+        line = {"metric": "stokes_matvec_gdofs", "value": value, "unit": "GDoF/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"cookbooks/convection_box_3d, global refinement {args.refinement}, "
+                                       f"{fin.n_cells} cells, {nu}+{npd} DoFs per GPU, per-q viscosity tables",
+                           "parallelism": "1 rank" if world == 1 else f"{world} independent subdomain replicas (no ghost exchange yet)"},
+                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, **extra}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
