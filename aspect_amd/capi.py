@@ -152,6 +152,11 @@ _PRODUCT = None
 
 
 def product_library_path():
+    # AGMG_LIB: developer knob for kernel ablation builds (tools/ablate.sh); still a HIP build of
+    # the same sources, never a CPU substitute
+    override = os.environ.get("AGMG_LIB")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaspect_amd.so")
 
 

@@ -181,7 +181,9 @@ struct agmg_ctx {
     return sync();
   }
 
+  bool use_blocks = true;
   void free_level(DeviceLevel &l);
+  int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv);
   int ensure_workspace();
   int ensure_transfers();
   int ensure_mg_vectors();
@@ -226,7 +228,97 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.coeff.etaT); dfree(l.inv_diag_A); dfree(l.inv_diag_M);
   dfree(l.prol_parent_v); dfree(l.prol_pos_v); dfree(l.prol_parent_p); dfree(l.prol_pos_p);
   dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
+  dfree(l.bt.blk_ptr); dfree(l.bt.blk_nexcl); dfree(l.bt.blk_sbase); dfree(l.bt.unodes); dfree(l.bt.uent8);
+  dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
   l = DeviceLevel();
+}
+
+// Block-scatter tables (agmg_internal.h BlockTables).  Blocks are runs of consecutive cells in the
+// host's cell order (Morton order keeps them compact); a velocity node is "exclusive" when all
+// cells touching it lie in one block.
+int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv) {
+  BlockTables &bt = lv.bt;
+  const int dim = lv.dim, NV = ipow(3, dim), nn = lv.n_nodes_v;
+  const int cpw = cells_per_wave(dim), bc = cpw * WAVES_PER_BLOCK;
+  const int nb = (lv.n_cells + bc - 1) / bc;
+  // pass 1: number of blocks touching each node
+  std::vector<int> last(nn, -1);
+  std::vector<uint8_t> nblk(nn, 0);
+  for (int b = 0; b < nb; ++b) {
+    const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
+    for (int cell = c0; cell < c1; ++cell)
+      for (int a = 0; a < NV; ++a) {
+        const uint32_t node = hl.cnv[(size_t)cell * NV + a];
+        if (last[node] != b) { last[node] = b; if (nblk[node] < 255) ++nblk[node]; }
+      }
+  }
+  // pass 2: per block unique nodes (exclusive first, each group ascending) and the CSR of LDS
+  // slots per node, in (cell, local dof) order
+  std::vector<uint32_t> blk_ptr(nb + 1, 0), blk_nexcl(nb, 0), blk_sbase(nb, 0), unodes;
+  std::vector<uint16_t> uent8;
+  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * NV * 64);
+  std::vector<int> lid_of(nn, -1);
+  std::fill(last.begin(), last.end(), -1);
+  std::vector<uint32_t> ex, sh, cnt, fillp;
+  std::vector<uint32_t> sh_count(nn, 0);
+  size_t nslots = 0;
+  int max_u = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> sh_pairs;  // (node, slot position)
+  for (int b = 0; b < nb; ++b) {
+    const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
+    ex.clear(); sh.clear();
+    for (int cell = c0; cell < c1; ++cell)
+      for (int a = 0; a < NV; ++a) {
+        const uint32_t node = hl.cnv[(size_t)cell * NV + a];
+        if (last[node] != b) { last[node] = b; (nblk[node] > 1 ? sh : ex).push_back(node); }
+      }
+    std::sort(ex.begin(), ex.end());
+    std::sort(sh.begin(), sh.end());
+    const int U = (int)(ex.size() + sh.size());
+    if (U > bc * NV / 2) return 0;  // (degenerate meshes) kernel's per-thread metadata bound: keep the slot path
+    max_u = std::max(max_u, U);
+    blk_ptr[b + 1] = blk_ptr[b] + U;
+    blk_nexcl[b] = (uint32_t)ex.size();
+    blk_sbase[b] = (uint32_t)nslots;
+    int lid = 0;
+    for (uint32_t node : ex) { lid_of[node] = lid++; unodes.push_back(node | ((uint32_t)cmv[node] << 29)); }
+    for (uint32_t node : sh) {
+      lid_of[node] = lid++;
+      unodes.push_back(node);
+      sh_pairs.emplace_back(node, (uint32_t)nslots++);
+      ++sh_count[node];
+    }
+    const size_t e0 = uent8.size();
+    uent8.resize(e0 + (size_t)U * 8, zero_slot);
+    cnt.assign(U, 0);
+    for (int cell = c0; cell < c1; ++cell) {
+      const int w = (cell - c0) / cpw, jj = (cell - c0) % cpw;
+      for (int a = 0; a < NV; ++a) {
+        const int l = lid_of[hl.cnv[(size_t)cell * NV + a]];
+        if (cnt[l] >= 8) return 0;  // node of valence > 8 inside one block: keep the slot path
+        uent8[e0 + (size_t)l * 8 + cnt[l]++] = (uint16_t)((w * NV + a) * 64 + jj * dim);
+      }
+    }
+  }
+  // fix-up CSR over shared nodes (ascending node order; slots of a node in block order)
+  std::vector<uint32_t> sh_nodes, sh_ptr(1, 0), sh_list(nslots);
+  std::vector<uint32_t> sh_index(nn, 0);
+  for (int node = 0; node < nn; ++node)
+    if (sh_count[node]) {
+      sh_index[node] = (uint32_t)sh_nodes.size();
+      sh_nodes.push_back((uint32_t)node | ((uint32_t)cmv[node] << 29));
+      sh_ptr.push_back(sh_ptr.back() + sh_count[node]);
+    }
+  std::vector<uint32_t> fill(sh_ptr.begin(), sh_ptr.end() - 1);
+  for (auto &pr : sh_pairs) sh_list[fill[sh_index[pr.first]]++] = pr.second;
+  bt.block_cells = bc; bt.n_blocks = nb; bt.max_unodes = max_u;
+  bt.n_shared = (int)sh_nodes.size(); bt.n_shared_slots = nslots;
+  CHECK(upload(&bt.blk_ptr, blk_ptr)); CHECK(upload(&bt.blk_nexcl, blk_nexcl)); CHECK(upload(&bt.blk_sbase, blk_sbase));
+  CHECK(upload(&bt.unodes, unodes)); CHECK(upload(&bt.uent8, uent8));
+  CHECK(upload(&bt.sh_nodes, sh_nodes)); CHECK(upload(&bt.sh_ptr, sh_ptr)); CHECK(upload(&bt.sh_list, sh_list));
+  bt.bytes = (blk_ptr.size() + blk_nexcl.size() + blk_sbase.size() + unodes.size() + sh_nodes.size() + sh_ptr.size() + sh_list.size()) * 4 + uent8.size() * 2;
+  bt.built = true;
+  return 0;
 }
 
 int agmg_ctx::ensure_workspace() {
@@ -352,10 +444,7 @@ int agmg_ctx::ensure_transfers() {
 // ===================================================================== operators
 int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e) {
   const DeviceLevel &lv = L[l];
-  if (which == 0) {
-    CHECK(launch_op_cells(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr));
-    return launch_pull_v(stream, lv, slots_u, e);
-  }
+  if (which == 0) return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks);
   CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
   return launch_pull_p(stream, lv, slots_p, 1, e);
 }
@@ -364,12 +453,11 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
 int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst) {
   const DeviceLevel &lv = fin();
   const size_t nu = lv.n_dofs_v();
-  CHECK(launch_op_cells(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p));
   EpiArgs eu = eu_in, ep = eu_in;
   eu.dst = dst; eu.x = src;
   ep.dst = dst + nu; ep.x = src + nu;
   if (eu_in.b) ep.b = eu_in.b + nu;
-  CHECK(launch_pull_v(stream, lv, slots_u, eu));
+  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks));
   return launch_pull_p(stream, lv, slots_p, lv.dim, ep);
 }
 int agmg_ctx::stokes_vmult(double *dst, const double *src) {
@@ -720,10 +808,9 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
   }
   CHECK(vec_scale(stream, dst_p, -1.0, np));
   {  // utmp = src_u - B^T dst_p
-    CHECK(launch_op_cells(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, dst_p, slots_u, nullptr));
     EpiArgs e;
     e.epi = EPI_RESID; e.dst = utmp; e.b = src_u; e.x = nullptr;
-    CHECK(launch_pull_v(stream, lv, slots_u, e));
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, dst_p, slots_u, nullptr, e, use_blocks));
   }
   if (expensive) {
     double nrm;
@@ -1042,6 +1129,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (hipSetDevice(opt->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
   auto *c = new agmg_ctx();
   c->opt = *opt;
+  if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
   c->L.resize(opt->n_levels);
   c->H.resize(opt->n_levels);
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
@@ -1153,6 +1241,8 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     hl.parent.assign(d->parent_cell, d->parent_cell + lv.n_cells);
     hl.child.assign(d->child_index, d->child_index + lv.n_cells);
   }
+  CHECK(c->build_block_tables(lv, hl, cmv));
+  lv.bytes_tables += lv.bt.bytes;
   CHECK(c->dalloc(&lv.inv_diag_A, (size_t)lv.n_dofs_v()));
   CHECK(c->dalloc(&lv.inv_diag_M, (size_t)lv.n_dofs_p()));
   lv.set = true;
@@ -1244,14 +1334,12 @@ int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const doub
     case AGMG_OP_A: return c->apply_level(0, l, cd, src, e);
     case AGMG_OP_MASS: return c->apply_level(1, l, cd, src, e);
     case AGMG_OP_STOKES: {
-      CHECK(launch_op_cells(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p));
-      CHECK(launch_pull_v(c->stream, lv, c->slots_u, e));
+      CHECK(launch_op(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p, e, c->use_blocks));
       e.dst = dst + nu; e.x = src + nu;
       return launch_pull_p(c->stream, lv, c->slots_p, lv.dim, e);
     }
     default: {  // B^T: both blocks of dst are written (vmult zeroes dst first)
-      CHECK(launch_op_cells(c->stream, lv, cd, AGMG_OP_BT, nullptr, src + nu, c->slots_u, nullptr));
-      CHECK(launch_pull_v(c->stream, lv, c->slots_u, e));
+      CHECK(launch_op(c->stream, lv, cd, AGMG_OP_BT, nullptr, src + nu, c->slots_u, nullptr, e, c->use_blocks));
       return vec_set(c->stream, dst + nu, 0.0, np);
     }
   }

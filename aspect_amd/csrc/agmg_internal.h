@@ -47,6 +47,27 @@ struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
   size_t bytes = 0;
 };
 
+// Block decomposition of the velocity nodes of one level ("block scatter"): cells are
+// cut into blocks of `block_cells` = WAVES_PER_BLOCK * (64 / dim) consecutive cells (one
+// workgroup); a block sums the contributions of its cells per node out of an LDS slot tile
+// (up to 8 slots per node, fixed order), stores nodes no other block touches ("exclusive")
+// straight to dst with the vector epilogue fused, and hands the partial sums of shared nodes to
+// a fix-up kernel.
+struct BlockTables {
+  bool built = false;
+  int block_cells = 0, n_blocks = 0, max_unodes = 0, n_shared = 0;
+  size_t n_shared_slots = 0;
+  uint32_t *blk_ptr = nullptr;    // [n_blocks + 1] offsets into unodes
+  uint32_t *blk_nexcl = nullptr;  // [n_blocks] number of exclusive nodes (they come first)
+  uint32_t *blk_sbase = nullptr;  // [n_blocks] first shared slot of the block
+  uint32_t *unodes = nullptr;     // global node of (block, local id)
+  uint16_t *uent8 = nullptr;      // per (block, local node) 8 LDS slot indices, padded with the zero slot
+  uint32_t *sh_nodes = nullptr;   // [n_shared] global node
+  uint32_t *sh_ptr = nullptr;     // [n_shared + 1]
+  uint32_t *sh_list = nullptr;    // slot positions, in block order
+  size_t bytes = 0;
+};
+
 struct DeviceLevel {
   bool set = false;
   int dim = 3;
@@ -66,6 +87,7 @@ struct DeviceLevel {
   uint32_t *pull_list_v = nullptr; // [n_cells * 3^dim]
   uint32_t *pull_ptr_p = nullptr;
   uint32_t *pull_list_p = nullptr; // [n_cells * 2^dim]
+  BlockTables bt;
   CoeffData coeff;
   double *inv_diag_A = nullptr, *inv_diag_M = nullptr;
   // transfer, stored on the FINE level: per fine node the parent cell (on
@@ -102,6 +124,11 @@ int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
 int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u,
                       double *slots_p);
 int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e);
+// Whole velocity-row application: cell phase + reduction + epilogue `eu` on the velocity rows.
+// Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.
+// Stokes pressure rows are left in slots_p for launch_pull_p(..., dim, ...).
+int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
+              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks);
 // n_parts: partial values per (cell, i) slot (dim for the Stokes pressure rows, 1 for mass)
 int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e);
 

@@ -18,6 +18,8 @@
 // each DoF in a fixed order and applies the vector epilogue.
 #include "agmg_internal.h"
 
+#include <cstdio>
+
 namespace agmg {
 
 namespace {
@@ -90,26 +92,38 @@ struct CellArgs {
 
 enum { KOP_STOKES = 0, KOP_A = 1, KOP_BT = 2 };
 
+// compile-time ablation switches for tools/ablate.sh (never defined in the product build)
+#ifndef AGMG_ABLATE
+#define AGMG_ABLATE 0
+#endif
+
+#if AGMG_ABLATE & 32
+#define AGMG_CELLS_WAVES 3
+#else
+#define AGMG_CELLS_WAVES 2
+#endif
+
+template <int DIM> struct KDims {
+  static constexpr int NV = (DIM == 3) ? 27 : 9;
+  static constexpr int NP = (DIM == 3) ? 8 : 4;
+  static constexpr int CPW = 64 / DIM;        // cells per wavefront
+  static constexpr int LROW = 64 * DIM + 2;   // padded row of the gradient-exchange tile
+  static constexpr int XB = 3 * LROW;         // doubles of exchange tile per wavefront
+};
+
+// One cell per DIM lanes: gather, sum-factorised evaluate, q-point operation, integrate.
+// Lane (j, c) of the wavefront handles component c of cell `cell`; G receives the 3^DIM velocity
+// contributions of that component, pout this lane's share of the 2^DIM pressure rows (Stokes).
+// xb: wave-private LDS tile [3][LROW] for the transpose of the velocity gradient.
 template <int DIM, int OP, bool COMP, bool PERQ>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArgs A) {
-  constexpr int NV = (DIM == 3) ? 27 : 9;
-  constexpr int NP = (DIM == 3) ? 8 : 4;
-  constexpr int NPL = NV / 3;   // points per plane (plane = last axis index fixed)
+__device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
+                                             const int lane, double (*xb)[KDims<DIM>::LROW], double *G,
+                                             double *pout) {
+  constexpr int NV = KDims<DIM>::NV;
+  constexpr int NP = KDims<DIM>::NP;
   constexpr int NPLP = NP / 2;  // pressure nodes per plane
-  constexpr int CPW = 64 / DIM;
-  constexpr int LROW = 64 * DIM + 2;
   constexpr bool HAS_U = (OP != KOP_BT);
   constexpr bool HAS_P = (OP != KOP_A);
-  __shared__ double xbuf[HAS_U ? WAVES_PER_BLOCK : 1][HAS_U ? 3 : 1][HAS_U ? LROW : 1];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int j = lane / DIM;
-  const int c = lane - j * DIM;
-  const bool lane_ok = j < CPW;
-  if (!lane_ok) j = CPW - 1;
-  const long cell_l = ((long)blockIdx.x * WAVES_PER_BLOCK + wave) * CPW + j;
-  const bool valid = lane_ok && cell_l < A.n_cells;
-  const int cell = cell_l < A.n_cells ? (int)cell_l : A.n_cells - 1;
   const size_t cs = (size_t)A.cstride;
 
   // geometry (MappingCartesian): ih[d] = 1 / (spacing * h_d)
@@ -136,8 +150,16 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArg
   if (HAS_U) {
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
+#if AGMG_ABLATE & 4
+      const uint32_t idx = (uint32_t)(cell + a);
+#else
       const uint32_t idx = A.cnvT[a * cs + cell];
+#endif
+#if AGMG_ABLATE & 2
+      const double v = (double)(idx & 1023u);
+#else
       const double v = A.src_u[(size_t)(idx & NODE_MASK) * DIM + c];
+#endif
       u[a] = ((idx >> (29 + c)) & 1u) ? 0.0 : v;
     }
     // nodal values -> values at the Gauss points, axis by axis
@@ -169,17 +191,17 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArg
       for (int b = 0; b < NPLP; ++b) pz[z][b] = fma(n1(z, 0), pin[b], n1(z, 1) * pin[NPLP + b]);
   }
 
-  double G[NV];
 #pragma unroll
   for (int a = 0; a < NV; ++a) G[a] = 0.0;
-  double pout[NP];
 #pragma unroll
   for (int b = 0; b < NP; ++b) pout[b] = 0.0;
 
   // one batch = one line of three Gauss points along axis 0
 #pragma unroll
   for (int L = 0; L < NV / 3; ++L) {
+#if !(AGMG_ABLATE & 16)
     __builtin_amdgcn_sched_barrier(0);
+#endif
     const int qy = (DIM == 3) ? L % 3 : L, qz = (DIM == 3) ? L / 3 : 0;
     const int base = 3 * L;
     double d[DIM][3];
@@ -221,7 +243,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArg
 #pragma unroll
         for (int dd = 0; dd < DIM; ++dd) {
           d[dd][x] *= ih[dd];
-          xbuf[wave][x][lane * DIM + dd] = d[dd][x];
+          xb[x][lane * DIM + dd] = d[dd][x];
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -231,17 +253,19 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArg
     for (int x = 0; x < 3; ++x) {
       const double wq = (DIM == 3) ? wq1(x) * wq1(qy) * wq1(qz) : wq1(x) * wq1(qy);
       double f = wq;
+#if !(AGMG_ABLATE & 8)
       if (PERQ) f *= A.etaT[(size_t)(base + x) * cs + cell];
+#endif
       if (HAS_U) {
         // column c of the velocity gradient: du_dd/dx_c lives in the lane of component dd
         double t[DIM];
 #pragma unroll
-        for (int dd = 0; dd < DIM; ++dd) t[dd] = d[dd][x] + xbuf[wave][x][(j * DIM + dd) * DIM + c];
+        for (int dd = 0; dd < DIM; ++dd) t[dd] = d[dd][x] + xb[x][(j * DIM + dd) * DIM + c];
         double fdiv = 0.0;
         if (COMP) {
           double div = 0.0;
 #pragma unroll
-          for (int e = 0; e < DIM; ++e) div += xbuf[wave][x][(j * DIM + e) * DIM + e];
+          for (int e = 0; e < DIM; ++e) div += xb[x][(j * DIM + e) * DIM + e];
           fdiv = f * div;
         }
 #pragma unroll
@@ -325,9 +349,31 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) k_cells(const CellArg
 #pragma unroll
     for (int l = 0; l < 9; ++l) interp3T(G[l], G[l + 9], G[l + 18]);
   }
+}
+
+// slot variant: every cell writes its contributions to slots [local dof][cell][component]
+template <int DIM, int OP, bool COMP, bool PERQ>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cells(const CellArgs A) {
+  constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
+  __shared__ double xbuf[WAVES_PER_BLOCK][3][LROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int j = lane / DIM;
+  const int c = lane - j * DIM;
+  const bool lane_ok = j < CPW;
+  if (!lane_ok) j = CPW - 1;
+  const long cell_l = ((long)blockIdx.x * WAVES_PER_BLOCK + wave) * CPW + j;
+  const bool valid = lane_ok && cell_l < A.n_cells;
+  const int cell = cell_l < A.n_cells ? (int)cell_l : A.n_cells - 1;
+  const size_t cs = (size_t)A.cstride;
+  double G[NV], pout[NP];
+  cell_compute<DIM, OP, COMP, PERQ>(A, cell, c, j, lane, xbuf[wave], G, pout);
   if (valid) {
 #pragma unroll
-    for (int a = 0; a < NV; ++a) A.slots_u[((size_t)a * cs + cell) * DIM + c] = G[a];
+    for (int a = 0; a < NV; ++a)
+#if AGMG_ABLATE & 1
+      if (G[a] == 12345.678)
+#endif
+      A.slots_u[((size_t)a * cs + cell) * DIM + c] = G[a];
     if (OP == KOP_STOKES) {
 #pragma unroll
       for (int b = 0; b < NP; ++b) A.slots_p[((size_t)b * cs + cell) * DIM + c] = pout[b];
@@ -447,6 +493,37 @@ struct PullArgs {
   EpiArgs e;
 };
 
+// vector epilogue shared by the pull, block and fix-up kernels; false = leave dst untouched
+__device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, const double sum, const bool con,
+                                          double &out) {
+  switch (e.epi) {
+    case EPI_STORE:
+      out = con ? (e.x ? e.x[t] : 0.0) : sum;
+      return true;
+    case EPI_RESID:
+      out = e.b[t] - (con ? (e.x ? e.x[t] : 0.0) : sum);
+      return true;
+    case EPI_CHEB: {
+      const double x = e.x[t];
+      const double Ax = con ? x : sum;
+      double v = fma(e.f2 * e.dinv[t], e.b[t] - Ax, (1.0 + e.f1) * x);
+      if (e.xold) v = fma(-e.f1, e.xold[t], v);
+      out = v;
+      return true;
+    }
+    case EPI_ADD:
+      if (con) return false;
+      out = e.dst[t] + sum;
+      return true;
+    case EPI_DIAG:
+      out = 1.0 / (con ? 1.0 : sum);
+      return true;
+    default:
+      out = con ? 1.0 : sum;
+      return true;
+  }
+}
+
 // NC: components per node (one thread each); NPARTS: partial values per slot summed by the thread
 template <int NC, int NPARTS>
 __global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
@@ -461,35 +538,181 @@ __global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
     for (int part = 0; part < NPARTS; ++part) sum += P.slots[base + part];
   }
   const bool con = P.cmask ? ((P.cmask[node] >> c) & 1u) : false;
-  const EpiArgs &e = P.e;
   double out;
-  switch (e.epi) {
-    case EPI_STORE:
-      out = con ? (e.x ? e.x[t] : 0.0) : sum;
-      break;
-    case EPI_RESID:
-      out = e.b[t] - (con ? (e.x ? e.x[t] : 0.0) : sum);
-      break;
-    case EPI_CHEB: {
-      const double x = e.x[t];
-      const double Ax = con ? x : sum;
-      double v = fma(e.f2 * e.dinv[t], e.b[t] - Ax, (1.0 + e.f1) * x);
-      if (e.xold) v = fma(-e.f1, e.xold[t], v);
-      out = v;
-      break;
+  if (epi_value(P.e, (size_t)t, sum, con, out)) P.e.dst[t] = out;
+}
+
+// ---- block scatter: one workgroup = WAVES_PER_BLOCK batches of cells ("block").  Every lane
+// parks its 3^DIM contributions in an LDS slot tile; after one barrier the workgroup sums, per
+// node of the block and in a fixed order, the slots that hit it (block-local CSR), stores nodes
+// no other block touches straight to dst with the vector epilogue fused, and hands the partial
+// sums of shared nodes to the fix-up kernel.  No atomics: results are bitwise reproducible.
+#if AGMG_ABLATE & 1024
+#define AGMG_STAMP(k)                                                                      \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    unsigned long long t_;                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if (lane == 0) B.dbg[((size_t)blockIdx.x * WAVES_PER_BLOCK + wave) * 8 + (k)] = t_;    \
+  } while (0)
+#else
+#define AGMG_STAMP(k)
+#endif
+struct BlkArgs {
+  unsigned long long *dbg;
+  const uint32_t *blk_ptr, *blk_nexcl, *blk_sbase, *unodes;
+  const uint4 *uent8;   // per (block, local node): 8 LDS slot indices (16 bit each)
+  double *slots_sh;
+};
+
+// LDS carve-up of k_cells_blk (bytes); max_u = largest number of unique nodes of any block
+template <int DIM> struct BlkLds {
+  static constexpr int BC = KDims<DIM>::CPW * WAVES_PER_BLOCK;
+  static constexpr int ZERO_SLOT = WAVES_PER_BLOCK * KDims<DIM>::NV * 64;   // slot index of a zero triple
+  static constexpr size_t slots = ((size_t)ZERO_SLOT + 4) * sizeof(double);
+  static_assert(KDims<DIM>::XB <= KDims<DIM>::NV * 64, "exchange tile must fit the wave's slot tile");
+  __host__ __device__ static size_t unodes_off(int max_u) { return slots + (size_t)max_u * 16; }
+  __host__ __device__ static size_t total(int max_u) { return unodes_off(max_u) + (size_t)max_u * 4; }
+};
+
+template <int DIM, int OP, bool COMP, bool PERQ>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES)
+k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u) {
+  constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
+  constexpr int BC = CPW * WAVES_PER_BLOCK, NT = 64 * WAVES_PER_BLOCK;
+  constexpr int MAXU_PT = (BC * NV / 2 + NT - 1) / NT;  // nodes per thread (U <= BC*NV/2, checked on the host)
+  extern __shared__ double smem[];
+  char *const smem_c = reinterpret_cast<char *>(smem);
+  double *const slots = smem;                                      // [wave][a][64] + zero triple
+  uint4 *const l_ent = reinterpret_cast<uint4 *>(smem_c + BlkLds<DIM>::slots);
+  uint32_t *const l_unodes = reinterpret_cast<uint32_t *>(smem_c + BlkLds<DIM>::unodes_off(max_u));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave's gradient-exchange tile aliases the head of its own slot tile: the tile is dead
+  // when the wave parks its results, and no other wave touches this slot tile before the barrier
+  double (*xb)[LROW] = reinterpret_cast<double (*)[LROW]>(slots + (size_t)wave * NV * 64);
+  int j = lane / DIM;
+  const int c = lane - j * DIM;
+  const bool lane_ok = j < CPW;
+  if (!lane_ok) j = CPW - 1;
+  const int blk = blockIdx.x;
+  const int c0 = blk * BC;
+  const int cell_l = c0 + wave * CPW + j;
+  const int cell = cell_l < A.n_cells ? cell_l : A.n_cells - 1;
+  const size_t cs = (size_t)A.cstride;
+  const uint32_t u0 = B.blk_ptr[blk];
+  const int U = (int)(B.blk_ptr[blk + 1] - u0);
+  const int nex = (int)B.blk_nexcl[blk];
+  AGMG_STAMP(0);
+  // block metadata: loads issued now, parked in LDS after the cell phase (latency hidden)
+  uint4 m_ent[MAXU_PT];
+  uint32_t m_node[MAXU_PT];
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int t = threadIdx.x + i * NT;
+    if (t < U) {
+      m_ent[i] = B.uent8[u0 + t];
+      m_node[i] = B.unodes[u0 + t];
     }
-    case EPI_ADD:
-      if (con) return;
-      out = e.dst[t] + sum;
-      break;
-    case EPI_DIAG:
-      out = 1.0 / (con ? 1.0 : sum);
-      break;
-    default:
-      out = con ? 1.0 : sum;
-      break;
   }
-  e.dst[t] = out;
+  if (threadIdx.x < 4) slots[BlkLds<DIM>::ZERO_SLOT + threadIdx.x] = 0.0;
+  {
+    double G[NV], pout[NP];
+    AGMG_STAMP(1);
+    cell_compute<DIM, OP, COMP, PERQ>(A, cell, c, j, lane, xb, G, pout);
+    AGMG_STAMP(2);
+    double *my = slots + (size_t)wave * NV * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) my[a * 64] = G[a];
+    if (OP == KOP_STOKES && lane_ok && cell_l < A.n_cells) {
+#pragma unroll
+      for (int bb = 0; bb < NP; ++bb) A.slots_p[((size_t)bb * cs + cell) * DIM + c] = pout[bb];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int t = threadIdx.x + i * NT;
+    if (t < U) {
+      l_ent[t] = m_ent[i];
+      l_unodes[t] = m_node[i];
+    }
+  }
+  AGMG_STAMP(3);
+  __syncthreads();
+  AGMG_STAMP(4);
+#if AGMG_ABLATE & 128
+  if (slots[threadIdx.x] != 12345.678) return;
+#endif
+  // node-owner sum out of the slot tile: one thread per node of the block, all DIM components;
+  // 8 slots per node in a fixed order (missing ones point at the zero triple)
+  const size_t sbase = (size_t)B.blk_sbase[blk] * DIM;
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int lid = threadIdx.x + i * NT;
+    if (lid < U) {
+      const uint4 e4 = l_ent[lid];
+      const uint32_t ew[4] = {e4.x, e4.y, e4.z, e4.w};
+      double sum[DIM];
+#pragma unroll
+      for (int cc = 0; cc < DIM; ++cc) sum[cc] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t ent = (k & 1) ? (ew[k >> 1] >> 16) : (ew[k >> 1] & 0xFFFFu);
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc) sum[cc] += slots[ent + cc];
+      }
+      if (lid < nex) {
+        const uint32_t nd = l_unodes[lid];
+        const size_t g0 = (size_t)(nd & NODE_MASK) * DIM;
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc) {
+          const bool con = (nd >> (29 + cc)) & 1u;
+          double out;
+#if AGMG_ABLATE & 512
+          if (sum[cc] == 12345.678)
+#endif
+          if (epi_value(E, g0 + cc, sum[cc], con, out)) E.dst[g0 + cc] = out;
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc)
+#if AGMG_ABLATE & 512
+          if (sum[cc] == 12345.678)
+#endif
+          B.slots_sh[sbase + (size_t)(lid - nex) * DIM + cc] = sum[cc];
+      }
+    }
+  }
+  AGMG_STAMP(5);
+}
+
+struct FixArgs {
+  const uint32_t *sh_nodes, *sh_ptr, *sh_list;
+  const double *slots_sh;
+  int n_shared;
+  EpiArgs e;
+};
+template <int NC>
+__global__ void __launch_bounds__(256) k_fix(const FixArgs F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F.n_shared) return;
+  const uint32_t s = F.sh_ptr[i], en = F.sh_ptr[i + 1];
+  const uint32_t nd = F.sh_nodes[i];   // node | cmask << 29
+  double sum[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) sum[c] = 0.0;
+  for (uint32_t k = s; k < en; ++k) {
+    const double *p = F.slots_sh + (size_t)F.sh_list[k] * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sum[c] += p[c];
+  }
+  const size_t g0 = (size_t)(nd & NODE_MASK) * NC;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool con = (nd >> (29 + c)) & 1u;
+    double out;
+    if (epi_value(F.e, g0 + c, sum[c], con, out)) F.e.dst[g0 + c] = out;
+  }
 }
 
 CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
@@ -520,6 +743,27 @@ void launch_cells_t(hipStream_t s, const CellArgs &a, bool comp, bool perq) {
     if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, false, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_cells<DIM, OP, false, false>), grid, block, 0, s, a);
   }
+}
+
+template <int DIM, int OP>
+int launch_blk_t(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiArgs &e, int n_blocks, int max_u,
+                 bool comp, bool perq) {
+  const size_t lds = BlkLds<DIM>::total(max_u);
+  const dim3 grid(n_blocks), block(64 * WAVES_PER_BLOCK);
+#define AGMG_BLK_LAUNCH(C, Q)                                                                              \
+  do {                                                                                                     \
+    static size_t lds_set = 0;                                                                             \
+    if (lds > lds_set) {                                                                                   \
+      AGMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_blk<DIM, OP, C, Q>),      \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+      lds_set = lds;                                                                                       \
+    }                                                                                                      \
+    hipLaunchKernelGGL((k_cells_blk<DIM, OP, C, Q>), grid, block, lds, s, a, b, e, max_u);                        \
+  } while (0)
+  if (comp) { if (perq) AGMG_BLK_LAUNCH(true, true); else AGMG_BLK_LAUNCH(true, false); }
+  else { if (perq) AGMG_BLK_LAUNCH(false, true); else AGMG_BLK_LAUNCH(false, false); }
+#undef AGMG_BLK_LAUNCH
+  return 0;
 }
 
 }  // namespace
@@ -604,6 +848,62 @@ int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int 
   else if (n_parts == 3) hipLaunchKernelGGL((k_pull<1, 3>), grid, block, 0, s, p);
   else { set_error("bad n_parts"); return -1; }
   AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
+              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks) {
+  if (!use_blocks || !L.bt.built) {
+    const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
+    if (rc) return rc;
+    return launch_pull_v(s, L, slots_u, eu);
+  }
+  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
+  if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
+  if (L.n_cells <= 0) return 0;
+  const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
+  const BlockTables &bt = L.bt;
+  static unsigned long long *dbg_buf = nullptr;
+#if AGMG_ABLATE & 1024
+  if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)4000000 * 8 * 8);
+#endif
+  BlkArgs b{dbg_buf, bt.blk_ptr, bt.blk_nexcl, bt.blk_sbase, bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), slots_u};
+  const bool perq = cd.nqv > 1;
+  const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
+  const int lds = bt.max_unodes;
+  int rc;
+  if (L.dim == 3) {
+    if (which == AGMG_OP_A) rc = launch_blk_t<3, KOP_A>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
+    else if (which == AGMG_OP_STOKES) rc = launch_blk_t<3, KOP_STOKES>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
+    else rc = launch_blk_t<3, KOP_BT>(s, a, b, eu, bt.n_blocks, lds, false, false);
+  } else {
+    if (which == AGMG_OP_A) rc = launch_blk_t<2, KOP_A>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
+    else if (which == AGMG_OP_STOKES) rc = launch_blk_t<2, KOP_STOKES>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
+    else rc = launch_blk_t<2, KOP_BT>(s, a, b, eu, bt.n_blocks, lds, false, false);
+  }
+  if (rc) return rc;
+  AGMG_HIP_CHECK(hipGetLastError());
+#if AGMG_ABLATE & 1024
+  {
+    (void)hipDeviceSynchronize();
+    const size_t nw = (size_t)bt.n_blocks * WAVES_PER_BLOCK;
+    std::vector<unsigned long long> h(nw * 8);
+    (void)hipMemcpy(h.data(), b.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    double d[5] = {0, 0, 0, 0, 0};
+    for (size_t w = 0; w < nw; ++w)
+      for (int k = 0; k < 5; ++k) d[k] += (double)(h[w * 8 + k + 1] - h[w * 8 + k]);
+    fprintf(stderr, "stamps (mean cycles/wave): meta-issue %.0f | cell_compute %.0f | park+meta->LDS %.0f | barrier %.0f | pull %.0f\n",
+            d[0] / nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw);
+  }
+#endif
+  if (bt.n_shared > 0) {
+    FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, bt.n_shared, eu};
+    const long n = (long)bt.n_shared;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (L.dim == 3) hipLaunchKernelGGL((k_fix<3>), grid, block, 0, s, f);
+    else hipLaunchKernelGGL((k_fix<2>), grid, block, 0, s, f);
+    AGMG_HIP_CHECK(hipGetLastError());
+  }
   return 0;
 }
 
