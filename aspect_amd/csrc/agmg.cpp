@@ -228,7 +228,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.coeff.etaT); dfree(l.inv_diag_A); dfree(l.inv_diag_M);
   dfree(l.prol_parent_v); dfree(l.prol_pos_v); dfree(l.prol_parent_p); dfree(l.prol_pos_p);
   dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
-  dfree(l.bt.blk_ptr); dfree(l.bt.blk_nexcl); dfree(l.bt.blk_sbase); dfree(l.bt.unodes); dfree(l.bt.uent8);
+  dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8);
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
   l = DeviceLevel();
 }
@@ -252,14 +252,13 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
         if (last[node] != b) { last[node] = b; if (nblk[node] < 255) ++nblk[node]; }
       }
   }
-  // pass 2: per block unique nodes (exclusive first, each group ascending) and the CSR of LDS
-  // slots per node, in (cell, local dof) order
-  std::vector<uint32_t> blk_ptr(nb + 1, 0), blk_nexcl(nb, 0), blk_sbase(nb, 0), unodes;
-  std::vector<uint16_t> uent8;
-  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * NV * 64);
+  // pass 2: per block unique nodes (exclusive first, each group ascending) and up to 8 LDS
+  // slots per node, in (cell, local dof) order.  Tables have a fixed stride max_u per block.
+  std::vector<std::vector<uint32_t>> bl_nodes(nb);
+  std::vector<uint32_t> blk_hdr((size_t)nb * 4, 0);
   std::vector<int> lid_of(nn, -1);
   std::fill(last.begin(), last.end(), -1);
-  std::vector<uint32_t> ex, sh, cnt, fillp;
+  std::vector<uint32_t> ex, sh;
   std::vector<uint32_t> sh_count(nn, 0);
   size_t nslots = 0;
   int max_u = 0;
@@ -277,28 +276,40 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
     const int U = (int)(ex.size() + sh.size());
     if (U > bc * NV / 2) return 0;  // (degenerate meshes) kernel's per-thread metadata bound: keep the slot path
     max_u = std::max(max_u, U);
-    blk_ptr[b + 1] = blk_ptr[b] + U;
-    blk_nexcl[b] = (uint32_t)ex.size();
-    blk_sbase[b] = (uint32_t)nslots;
-    int lid = 0;
-    for (uint32_t node : ex) { lid_of[node] = lid++; unodes.push_back(node | ((uint32_t)cmv[node] << 29)); }
+    blk_hdr[(size_t)b * 4 + 0] = (uint32_t)U;
+    blk_hdr[(size_t)b * 4 + 1] = (uint32_t)ex.size();
+    blk_hdr[(size_t)b * 4 + 2] = (uint32_t)nslots;
+    bl_nodes[b] = ex;
+    bl_nodes[b].insert(bl_nodes[b].end(), sh.begin(), sh.end());
     for (uint32_t node : sh) {
-      lid_of[node] = lid++;
-      unodes.push_back(node);
       sh_pairs.emplace_back(node, (uint32_t)nslots++);
       ++sh_count[node];
     }
-    const size_t e0 = uent8.size();
-    uent8.resize(e0 + (size_t)U * 8, zero_slot);
+  }
+  const int wtile = blk_wave_tile(dim);
+  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile);
+  std::vector<uint32_t> unodes((size_t)nb * max_u, 0);
+  std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot);
+  std::vector<uint8_t> cnt;
+  for (int b = 0; b < nb; ++b) {
+    const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
+    const size_t m0 = (size_t)b * max_u;
+    const int U = (int)bl_nodes[b].size();
+    for (int l = 0; l < U; ++l) {
+      const uint32_t node = bl_nodes[b][l];
+      lid_of[node] = l;
+      unodes[m0 + l] = node | ((uint32_t)cmv[node] << 29);
+    }
     cnt.assign(U, 0);
     for (int cell = c0; cell < c1; ++cell) {
       const int w = (cell - c0) / cpw, jj = (cell - c0) % cpw;
       for (int a = 0; a < NV; ++a) {
         const int l = lid_of[hl.cnv[(size_t)cell * NV + a]];
         if (cnt[l] >= 8) return 0;  // node of valence > 8 inside one block: keep the slot path
-        uent8[e0 + (size_t)l * 8 + cnt[l]++] = (uint16_t)((w * NV + a) * 64 + jj * dim);
+        uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)(w * wtile + a * 64 + jj * dim);
       }
     }
+    std::vector<uint32_t>().swap(bl_nodes[b]);
   }
   // fix-up CSR over shared nodes (ascending node order; slots of a node in block order)
   std::vector<uint32_t> sh_nodes, sh_ptr(1, 0), sh_list(nslots);
@@ -313,10 +324,10 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   for (auto &pr : sh_pairs) sh_list[fill[sh_index[pr.first]]++] = pr.second;
   bt.block_cells = bc; bt.n_blocks = nb; bt.max_unodes = max_u;
   bt.n_shared = (int)sh_nodes.size(); bt.n_shared_slots = nslots;
-  CHECK(upload(&bt.blk_ptr, blk_ptr)); CHECK(upload(&bt.blk_nexcl, blk_nexcl)); CHECK(upload(&bt.blk_sbase, blk_sbase));
+  CHECK(upload(&bt.blk_hdr, blk_hdr));
   CHECK(upload(&bt.unodes, unodes)); CHECK(upload(&bt.uent8, uent8));
   CHECK(upload(&bt.sh_nodes, sh_nodes)); CHECK(upload(&bt.sh_ptr, sh_ptr)); CHECK(upload(&bt.sh_list, sh_list));
-  bt.bytes = (blk_ptr.size() + blk_nexcl.size() + blk_sbase.size() + unodes.size() + sh_nodes.size() + sh_ptr.size() + sh_list.size()) * 4 + uent8.size() * 2;
+  bt.bytes = (blk_hdr.size() + unodes.size() + sh_nodes.size() + sh_ptr.size() + sh_list.size()) * 4 + uent8.size() * 2;
   bt.built = true;
   return 0;
 }

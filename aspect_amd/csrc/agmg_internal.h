@@ -26,7 +26,15 @@ constexpr uint32_t NODE_MASK = 0x1FFFFFFFu;  // low 29 bits: node index; high 3 
 constexpr int WAVES_PER_BLOCK = 4;
 // cell kernels: one lane per (cell, velocity component); 21 cells (3-D) or 32
 // cells (2-D) per 64-lane wavefront
-inline int cells_per_wave(int dim) { return 64 / dim; }
+constexpr int cells_per_wave(int dim) { return 64 / dim; }
+// doubles of LDS per wavefront in the block-scatter kernel: the slot tile [3^dim][64], which also
+// hosts (aliased, earlier in the wave's life) the gradient-exchange tile [3][64*dim+2] and the
+// per-q viscosity tile [3^dim][cells_per_wave]
+constexpr int blk_wave_tile(int dim) {
+  const int nv = dim == 3 ? 27 : 9;
+  const int slots = nv * 64, scratch = 3 * (64 * dim + 2) + nv * cells_per_wave(dim);
+  return ((slots > scratch ? slots : scratch) + 7) / 8 * 8;
+}
 
 // epilogues of the pull (node-owner) kernels
 enum Epilogue {
@@ -57,11 +65,9 @@ struct BlockTables {
   bool built = false;
   int block_cells = 0, n_blocks = 0, max_unodes = 0, n_shared = 0;
   size_t n_shared_slots = 0;
-  uint32_t *blk_ptr = nullptr;    // [n_blocks + 1] offsets into unodes
-  uint32_t *blk_nexcl = nullptr;  // [n_blocks] number of exclusive nodes (they come first)
-  uint32_t *blk_sbase = nullptr;  // [n_blocks] first shared slot of the block
-  uint32_t *unodes = nullptr;     // global node of (block, local id)
-  uint16_t *uent8 = nullptr;      // per (block, local node) 8 LDS slot indices, padded with the zero slot
+  uint32_t *blk_hdr = nullptr;    // [n_blocks][4]: unique nodes, exclusive nodes (they come first), first shared slot, 0
+  uint32_t *unodes = nullptr;     // [n_blocks][max_unodes] global node | cmask << 29 of (block, local id)
+  uint16_t *uent8 = nullptr;      // [n_blocks][max_unodes][8] LDS slot indices, padded with the zero slot
   uint32_t *sh_nodes = nullptr;   // [n_shared] global node
   uint32_t *sh_ptr = nullptr;     // [n_shared + 1]
   uint32_t *sh_list = nullptr;    // slot positions, in block order

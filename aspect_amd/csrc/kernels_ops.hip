@@ -115,10 +115,13 @@ template <int DIM> struct KDims {
 // Lane (j, c) of the wavefront handles component c of cell `cell`; G receives the 3^DIM velocity
 // contributions of that component, pout this lane's share of the 2^DIM pressure rows (Stokes).
 // xb: wave-private LDS tile [3][LROW] for the transpose of the velocity gradient.
-template <int DIM, int OP, bool COMP, bool PERQ>
+// eta_tile (ETA_LDS): wave-private LDS copy [q][CPW] of the per-q viscosities of the wave's cells.
+// mid(): called once after the gather loads are issued (the block kernel parks prefetched
+// tables in LDS there, under the gather latency).
+template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, class Mid>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, double (*xb)[KDims<DIM>::LROW], double *G,
-                                             double *pout) {
+                                             double *pout, const double *eta_tile, Mid &&mid) {
   constexpr int NV = KDims<DIM>::NV;
   constexpr int NP = KDims<DIM>::NP;
   constexpr int NPLP = NP / 2;  // pressure nodes per plane
@@ -162,6 +165,9 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #endif
       u[a] = ((idx >> (29 + c)) & 1u) ? 0.0 : v;
     }
+  }
+  mid();
+  if (HAS_U) {
     // nodal values -> values at the Gauss points, axis by axis
 #pragma unroll
     for (int l = 0; l < NV / 3; ++l) interp3(u[3 * l], u[3 * l + 1], u[3 * l + 2]);
@@ -254,7 +260,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       const double wq = (DIM == 3) ? wq1(x) * wq1(qy) * wq1(qz) : wq1(x) * wq1(qy);
       double f = wq;
 #if !(AGMG_ABLATE & 8)
-      if (PERQ) f *= A.etaT[(size_t)(base + x) * cs + cell];
+      if (PERQ) f *= ETA_LDS ? eta_tile[(base + x) * KDims<DIM>::CPW + j] : A.etaT[(size_t)(base + x) * cs + cell];
 #endif
       if (HAS_U) {
         // column c of the velocity gradient: du_dd/dx_c lives in the lane of component dd
@@ -366,7 +372,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cell
   const int cell = cell_l < A.n_cells ? (int)cell_l : A.n_cells - 1;
   const size_t cs = (size_t)A.cstride;
   double G[NV], pout[NP];
-  cell_compute<DIM, OP, COMP, PERQ>(A, cell, c, j, lane, xbuf[wave], G, pout);
+  cell_compute<DIM, OP, COMP, PERQ, false>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, [] {});
   if (valid) {
 #pragma unroll
     for (int a = 0; a < NV; ++a)
@@ -561,17 +567,21 @@ __global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
 #endif
 struct BlkArgs {
   unsigned long long *dbg;
-  const uint32_t *blk_ptr, *blk_nexcl, *blk_sbase, *unodes;
-  const uint4 *uent8;   // per (block, local node): 8 LDS slot indices (16 bit each)
+  const uint4 *blk_hdr;      // per block {unique nodes, exclusive nodes, first shared slot, 0}
+  const uint32_t *unodes;    // [n_blocks][max_u]: node | cmask << 29
+  const uint4 *uent8;        // [n_blocks][max_u]: 8 LDS slot indices (16 bit each) per local node
   double *slots_sh;
 };
 
 // LDS carve-up of k_cells_blk (bytes); max_u = largest number of unique nodes of any block
 template <int DIM> struct BlkLds {
   static constexpr int BC = KDims<DIM>::CPW * WAVES_PER_BLOCK;
-  static constexpr int ZERO_SLOT = WAVES_PER_BLOCK * KDims<DIM>::NV * 64;   // slot index of a zero triple
+  static constexpr int WTILE = blk_wave_tile(DIM);                          // doubles per wavefront
+  static constexpr int ZERO_SLOT = WAVES_PER_BLOCK * WTILE;                 // slot index of a zero triple
   static constexpr size_t slots = ((size_t)ZERO_SLOT + 4) * sizeof(double);
-  static_assert(KDims<DIM>::XB <= KDims<DIM>::NV * 64, "exchange tile must fit the wave's slot tile");
+  static constexpr int ETA_OFF = KDims<DIM>::XB;                             // eta tile behind the exchange tile
+  static_assert(KDims<DIM>::XB + KDims<DIM>::NV * KDims<DIM>::CPW <= WTILE && KDims<DIM>::NV * 64 <= WTILE,
+                "exchange + eta tiles and the slot tile must fit the wave's tile");
   __host__ __device__ static size_t unodes_off(int max_u) { return slots + (size_t)max_u * 16; }
   __host__ __device__ static size_t total(int max_u) { return unodes_off(max_u) + (size_t)max_u * 4; }
 };
@@ -582,15 +592,20 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
   constexpr int BC = CPW * WAVES_PER_BLOCK, NT = 64 * WAVES_PER_BLOCK;
   constexpr int MAXU_PT = (BC * NV / 2 + NT - 1) / NT;  // nodes per thread (U <= BC*NV/2, checked on the host)
+  constexpr int NETA = NV * CPW, NETA_PL = (NETA + 63) / 64;
+  constexpr bool ETA_LDS = PERQ && (OP != KOP_BT);
   extern __shared__ double smem[];
   char *const smem_c = reinterpret_cast<char *>(smem);
   double *const slots = smem;                                      // [wave][a][64] + zero triple
   uint4 *const l_ent = reinterpret_cast<uint4 *>(smem_c + BlkLds<DIM>::slots);
   uint32_t *const l_unodes = reinterpret_cast<uint32_t *>(smem_c + BlkLds<DIM>::unodes_off(max_u));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the wave's gradient-exchange tile aliases the head of its own slot tile: the tile is dead
-  // when the wave parks its results, and no other wave touches this slot tile before the barrier
-  double (*xb)[LROW] = reinterpret_cast<double (*)[LROW]>(slots + (size_t)wave * NV * 64);
+  // the wave's gradient-exchange tile and its viscosity tile alias the head of its own slot
+  // tile: both are dead when the wave parks its results, and no other wave touches this slot
+  // tile before the barrier
+  double *const wtile = slots + (size_t)wave * BlkLds<DIM>::WTILE;
+  double (*xb)[LROW] = reinterpret_cast<double (*)[LROW]>(wtile);
+  double *const eta_tile = wtile + BlkLds<DIM>::ETA_OFF;
   int j = lane / DIM;
   const int c = lane - j * DIM;
   const bool lane_ok = j < CPW;
@@ -600,41 +615,63 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   const int cell_l = c0 + wave * CPW + j;
   const int cell = cell_l < A.n_cells ? cell_l : A.n_cells - 1;
   const size_t cs = (size_t)A.cstride;
-  const uint32_t u0 = B.blk_ptr[blk];
-  const int U = (int)(B.blk_ptr[blk + 1] - u0);
-  const int nex = (int)B.blk_nexcl[blk];
   AGMG_STAMP(0);
-  // block metadata: loads issued now, parked in LDS after the cell phase (latency hidden)
+  // prefetch, in issue order: per-q viscosities of the wave's cells, block tables (fixed stride
+  // max_u per block: no dependent address), then the cell's own loads inside cell_compute
+  double m_eta[ETA_LDS ? NETA_PL : 1];
+  if (ETA_LDS) {
+#pragma unroll
+    for (int k = 0; k < NETA_PL; ++k) {
+      const int idx = lane + 64 * k;
+      const int q = idx / CPW, jj = idx - q * CPW;
+      const int cx = min(c0 + wave * CPW + jj, A.cstride - 1);
+      m_eta[k] = idx < NETA ? A.etaT[(size_t)q * cs + cx] : 0.0;
+    }
+  }
   uint4 m_ent[MAXU_PT];
   uint32_t m_node[MAXU_PT];
+  const size_t mbase = (size_t)blk * max_u;
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) {
     const int t = threadIdx.x + i * NT;
-    if (t < U) {
-      m_ent[i] = B.uent8[u0 + t];
-      m_node[i] = B.unodes[u0 + t];
+    if (t < max_u) {
+      m_ent[i] = B.uent8[mbase + t];
+      m_node[i] = B.unodes[mbase + t];
     }
   }
+  const uint4 hdr = B.blk_hdr[blk];
+  const int U = (int)hdr.x, nex = (int)hdr.y;
   if (threadIdx.x < 4) slots[BlkLds<DIM>::ZERO_SLOT + threadIdx.x] = 0.0;
   {
     double G[NV], pout[NP];
     AGMG_STAMP(1);
-    cell_compute<DIM, OP, COMP, PERQ>(A, cell, c, j, lane, xb, G, pout);
+    cell_compute<DIM, OP, COMP, PERQ, ETA_LDS>(A, cell, c, j, lane, xb, G, pout, eta_tile, [&] {
+      if (ETA_LDS) {
+#pragma unroll
+        for (int k = 0; k < NETA_PL; ++k) {
+          const int idx = lane + 64 * k;
+          if (idx < NETA) eta_tile[idx] = m_eta[k];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAXU_PT; ++i) {
+        const int t = threadIdx.x + i * NT;
+        if (t < max_u) {
+          l_ent[t] = m_ent[i];
+          l_unodes[t] = m_node[i];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    });
     AGMG_STAMP(2);
-    double *my = slots + (size_t)wave * NV * 64 + lane;
+    double *my = wtile + lane;
 #pragma unroll
     for (int a = 0; a < NV; ++a) my[a * 64] = G[a];
     if (OP == KOP_STOKES && lane_ok && cell_l < A.n_cells) {
 #pragma unroll
       for (int bb = 0; bb < NP; ++bb) A.slots_p[((size_t)bb * cs + cell) * DIM + c] = pout[bb];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MAXU_PT; ++i) {
-    const int t = threadIdx.x + i * NT;
-    if (t < U) {
-      l_ent[t] = m_ent[i];
-      l_unodes[t] = m_node[i];
     }
   }
   AGMG_STAMP(3);
@@ -645,7 +682,7 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
 #endif
   // node-owner sum out of the slot tile: one thread per node of the block, all DIM components;
   // 8 slots per node in a fixed order (missing ones point at the zero triple)
-  const size_t sbase = (size_t)B.blk_sbase[blk] * DIM;
+  const size_t sbase = (size_t)hdr.z * DIM;
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) {
     const int lid = threadIdx.x + i * NT;
@@ -867,7 +904,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
 #if AGMG_ABLATE & 1024
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)4000000 * 8 * 8);
 #endif
-  BlkArgs b{dbg_buf, bt.blk_ptr, bt.blk_nexcl, bt.blk_sbase, bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), slots_u};
+  BlkArgs b{dbg_buf, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), slots_u};
   const bool perq = cd.nqv > 1;
   const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
   const int lds = bt.max_unodes;
