@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Extracts the facts the reference's own regression goldens pin for the block-GMG Stokes solve
+(tests/<name>/screen-output of tjhei/aspect 3.1.0-pre) into tests/golden/gmg_goldens.json.
+Only numbers are kept (data, not source).  Run in the build container, where /root/reference
+exists:   python tests/golden/make_goldens.py"""
+import json
+import os
+import re
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", "nsinker_gmg_idr",
+         "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
+         "particle_interpolator_bilinear_3d"]
+
+
+def parse(path):
+    out = {"solves": []}
+    cur = None
+    for line in open(path):
+        m = re.search(r"Number of active cells: ([\d,]+) \(on (\d+) levels\)", line)
+        if m:
+            out.setdefault("meshes", []).append({"cells": int(m.group(1).replace(",", "")), "levels": int(m.group(2))})
+        m = re.search(r"Number of degrees of freedom: ([\d,]+) \(([\d,+]+)\)", line)
+        if m:
+            parts = [int(x.replace(",", "")) for x in m.group(2).split("+")]
+            out["meshes"][-1]["dofs_u"], out["meshes"][-1]["dofs_p"] = parts[0], parts[1]
+        if "Solving Stokes system (GMG" in line:
+            cur = {"mesh": len(out.get("meshes", [])) - 1}
+            out["solves"].append(cur)
+            m = re.search(r"\.\.\.\s*(\d+)\+(\d+) iterations", line)
+            if m:
+                cur["cheap"], cur["expensive"] = int(m.group(1)), int(m.group(2))
+        if cur is None:
+            continue
+        m = re.search(r"GMG coarse size A: (\d+), coarse size S: (\d+)", line)
+        if m:
+            cur["coarse_A"], cur["coarse_S"] = int(m.group(1)), int(m.group(2))
+        m = re.search(r"GMG n_levels: (\d+)", line)
+        if m:
+            cur["n_levels"] = int(m.group(1))
+        m = re.search(r"Viscosity range: (\S+) - (\S+)", line)
+        if m:
+            cur["eta_min"], cur["eta_max"] = float(m.group(1)), float(m.group(2))
+        m = re.search(r"Stokes solver: (\d+)\+(\d+) iterations", line)
+        if m:
+            cur["cheap"], cur["expensive"] = int(m.group(1)), int(m.group(2))
+        m = re.search(r"Schur complement preconditioner: (\d+)\+(\d+) iterations", line)
+        if m:
+            cur["S_cheap"], cur["S_expensive"] = int(m.group(1)), int(m.group(2))
+        m = re.search(r"A block preconditioner: (\d+)\+(\d+) iterations", line)
+        if m:
+            cur["A_cheap"], cur["A_expensive"] = int(m.group(1)), int(m.group(2))
+        m = re.search(r"Relative nonlinear residual \(Stokes system\) after nonlinear iteration (\d+): (\S+)", line)
+        if m:
+            out.setdefault("nonlinear_residuals", []).append(float(m.group(2)))
+        m = re.search(r"Errors u_L1, p_L1, u_L2, p_L2:?\s+(\S+),\s*(\S+),\s*(\S+),\s*(\S+)", line)
+        if m:
+            out["errors_uL1_pL1_uL2_pL2"] = [float(m.group(i)) for i in range(1, 5)]
+    return out
+
+
+def main():
+    res = {"_source": "tjhei/aspect 3.1.0-pre tests/<case>/screen-output (deal.II 9.6 goldens)"}
+    for c in CASES:
+        res[c] = parse(os.path.join(REF, "tests", c, "screen-output"))
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gmg_goldens.json")
+    json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+"""CPU suite, part 1: the oracle (oracle/oracle.cpp) against the reference's own regression
+goldens (tests/golden/gmg_goldens.json, extracted from tjhei/aspect tests/*/screen-output by
+tests/golden/make_goldens.py) and against its independent dense restatement of the bilinear form.
+The reference holds no operator-level golden vectors for this path: iteration
+counts, DoF counts, coarse sizes and viscosity ranges are what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from aspect_amd import boxmesh as bm
+from aspect_amd import capi, cases
+from oracle import pyoracle
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gmg_goldens.json")))
+
+
+def solve(problem):
+    problem.build()
+    s = pyoracle.solver(problem)
+    x, rep, rc = s.solve(allow_failure=True)
+    s.close()
+    return problem, rep, rc
+
+
+def check_mesh(problem, gold_mesh):
+    fin = problem.hier.finest
+    assert fin.n_cells == gold_mesh["cells"]
+    assert fin.n_dofs_v == gold_mesh["dofs_u"]
+    assert fin.n_dofs_p == gold_mesh["dofs_p"]
+    assert problem.hier.n_levels == gold_mesh["levels"]
+
+
+@pytest.mark.parametrize("case,refinement,kw", [
+    ("sol_cx_2_gmg", 2, {}),
+    ("sol_cx_4_gmg", 4, {}),
+    ("sol_cx_4_gmg_no_avg", 4, {"averaging": bm.AVG_NONE}),
+])
+def test_solcx_iterations(case, refinement, kw):
+    g = G[case]
+    p, rep, rc = solve(cases.solcx(refinement, **kw))
+    check_mesh(p, g["meshes"][0])
+    assert rc == 0
+    assert abs(rep.n_cheap_iterations - g["solves"][0]["cheap"]) <= 1
+    assert rep.n_expensive_iterations == g["solves"][0]["expensive"] == 0
+
+
+def test_no_cheap_expensive_path():
+    g = G["no_cheap_gmg"]
+    p, rep, rc = solve(cases.solcx(4, n_cheap=0))
+    check_mesh(p, g["meshes"][0])
+    assert rc == 0
+    assert rep.n_cheap_iterations == 0
+    assert abs(rep.n_expensive_iterations - g["solves"][0]["expensive"]) <= 1
+
+
+def test_nsinker_idr_viscosity_range_and_vcycles():
+    g = G["nsinker_gmg_idr"]
+    s0 = g["solves"][0]
+    # both nsinker tests include benchmarks/nsinker/nsinker_gmg.prm: tol 1e-6, 200 cheap steps,
+    # 0 expensive, restart 100 (the defaults of cases.nsinker_box)
+    p, rep, rc = solve(cases.nsinker_box(2, n_sinkers=4, ratio=1e4, krylov="idr"))
+    check_mesh(p, g["meshes"][0])
+    # "Viscosity range: 0.01 - 0.198921" pins viscosity evaluation + harmonic averaging + quadrature
+    assert abs(p.eta_min - s0["eta_min"]) <= 5e-7 and abs(p.eta_max - s0["eta_max"]) <= 5e-7
+    lev0 = p.hier.levels[0]
+    assert lev0.n_dofs_v == s0["coarse_A"] and lev0.n_dofs_p == s0["coarse_S"]
+    assert p.hier.n_levels == s0["n_levels"]
+    assert abs(rep.n_cheap_iterations - s0["cheap"]) <= 1
+    # IDR(2) spends s + 1 = 3 V-cycles per full step and its shadow space is random (deal.II draws
+    # it from boost::random, the oracle from std::mt19937): one step of slack = up to 5 V-cycles
+    assert abs(rep.n_A_preconditioner_cheap - s0["A_cheap"]) <= 5
+    assert rep.n_A_preconditioner_cheap == rep.n_S_preconditioner_cheap
+
+
+def test_nsinker_no_averaging():
+    g = G["nsinker_gmg_no_avg"]
+    s0 = g["solves"][0]
+    p, rep, rc = solve(cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE))
+    assert abs(p.eta_min - s0["eta_min"]) <= 5e-7 and abs(p.eta_max - s0["eta_max"]) <= 5e-5
+    assert abs(rep.n_cheap_iterations - s0["cheap"]) <= 1
+    # right-preconditioned GMRES: V-cycles = N + ceil(N / restart)  
+    n = rep.n_cheap_iterations
+    assert rep.n_A_preconditioner_cheap == n + -(-n // p.restart)
+    assert s0["A_cheap"] == s0["cheap"] + -(-s0["cheap"] // 100)
+
+
+@pytest.mark.parametrize("case,make", [
+    ("stokes", lambda: cases.stokes_sinker_box(2)),
+    ("refinement_nonadiabatic_temperature", lambda: cases.convection_box(2, 3)),
+    ("particle_interpolator_bilinear_3d", lambda: cases.convection_box(3, 3)),
+])
+def test_isoviscous_free_slip_boxes(case, make):
+    """default settings: local smoothing, Q1-projected (per-q) viscosity, tol 1e-7, GMRES(100)."""
+    g = G[case]
+    p, rep, rc = solve(make())
+    check_mesh(p, g["meshes"][0])
+    assert rc == 0
+    assert abs(rep.n_cheap_iterations - g["solves"][0]["cheap"]) <= 1
+
+
+@pytest.mark.parametrize("make", [
+    lambda: cases.nsinker_box(1, n_sinkers=4, ratio=1e4),
+    lambda: cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE),
+    lambda: cases.convection_box(2, 2),
+    lambda: cases.solcx(2),
+])
+def test_sum_factorised_operators_equal_dense_bilinear_form(make):
+    """oracle pair of SURVEY.md 8c item 5: sum-factorised apply (matrix_free_operators.cc) vs an
+    independent dense cell-matrix assembly of assemblers/stokes.cc:463-479."""
+    p = make().build()
+    s = pyoracle.solver(p)
+    rng = np.random.Generator(np.random.PCG64(2025))
+    for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT, capi.OP_MASS):
+        src = rng.uniform(-1, 1, s.size(which))
+        a, b = s.vmult(which, src), s.vmult(which, src, dense=True)
+        if which == capi.OP_BT:       # the dense path leaves the pressure block of B^T untouched
+            nu = p.hier.finest.n_dofs_v
+            a, b = a[:nu], b[:nu]
+        assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(b)
+    s.close()
+
+
+def test_operator_properties():
+    """size-independent properties: A and the mass matrix are symmetric positive on unconstrained
+    rows, B^T is the transpose of the (u -> p) block of the Stokes operator."""
+    p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4).build()
+    s = pyoracle.solver(p)
+    fin = p.hier.finest
+    nu = fin.n_dofs_v
+    free = ~fin.constrained_dofs_v()
+    rng = np.random.Generator(np.random.PCG64(7))
+    x, y = rng.uniform(-1, 1, nu) * free, rng.uniform(-1, 1, nu) * free
+    ax, ay = s.vmult(capi.OP_A, x), s.vmult(capi.OP_A, y)
+    assert abs(y @ ax - x @ ay) <= 1e-12 * abs(y @ ax)
+    assert x @ ax > 0
+    q = rng.uniform(-1, 1, fin.n_dofs_p)
+    bt = s.vmult(capi.OP_BT, np.concatenate([np.zeros(nu), q]))[:nu]
+    st = s.vmult(capi.OP_STOKES, np.concatenate([x, np.zeros(fin.n_dofs_p)]))[nu:]
+    assert abs(x @ bt - q @ st) <= 1e-12 * abs(x @ bt)
+    s.close()
