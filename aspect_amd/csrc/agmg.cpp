@@ -228,7 +228,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.coeff.etaT); dfree(l.inv_diag_A); dfree(l.inv_diag_M);
   dfree(l.prol_parent_v); dfree(l.prol_pos_v); dfree(l.prol_parent_p); dfree(l.prol_pos_p);
   dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
-  dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8);
+  dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8); dfree(l.bt.lidT);
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
   l = DeviceLevel();
 }
@@ -287,9 +287,9 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
     }
   }
   const int wtile = blk_wave_tile(dim);
-  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile);
+  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile * 8);  // entries are LDS byte offsets
   std::vector<uint32_t> unodes((size_t)nb * max_u, 0);
-  std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot);
+  std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot), lidT((size_t)NV * lv.cstride, 0);
   std::vector<uint8_t> cnt;
   for (int b = 0; b < nb; ++b) {
     const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
@@ -305,8 +305,9 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
       const int w = (cell - c0) / cpw, jj = (cell - c0) % cpw;
       for (int a = 0; a < NV; ++a) {
         const int l = lid_of[hl.cnv[(size_t)cell * NV + a]];
+        lidT[(size_t)a * lv.cstride + cell] = (uint16_t)l;
         if (cnt[l] >= 8) return 0;  // node of valence > 8 inside one block: keep the slot path
-        uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)(w * wtile + a * 64 + jj * dim);
+        uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)((w * wtile + a * BLK_SLOT_ROW + jj * dim) * 8);
       }
     }
     std::vector<uint32_t>().swap(bl_nodes[b]);
@@ -325,9 +326,9 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   bt.block_cells = bc; bt.n_blocks = nb; bt.max_unodes = max_u;
   bt.n_shared = (int)sh_nodes.size(); bt.n_shared_slots = nslots;
   CHECK(upload(&bt.blk_hdr, blk_hdr));
-  CHECK(upload(&bt.unodes, unodes)); CHECK(upload(&bt.uent8, uent8));
+  CHECK(upload(&bt.unodes, unodes)); CHECK(upload(&bt.uent8, uent8)); CHECK(upload(&bt.lidT, lidT));
   CHECK(upload(&bt.sh_nodes, sh_nodes)); CHECK(upload(&bt.sh_ptr, sh_ptr)); CHECK(upload(&bt.sh_list, sh_list));
-  bt.bytes = (blk_hdr.size() + unodes.size() + sh_nodes.size() + sh_ptr.size() + sh_list.size()) * 4 + uent8.size() * 2;
+  bt.bytes = (blk_hdr.size() + unodes.size() + sh_nodes.size() + sh_ptr.size() + sh_list.size()) * 4 + (uent8.size() + lidT.size()) * 2;
   bt.built = true;
   return 0;
 }

@@ -116,12 +116,12 @@ template <int DIM> struct KDims {
 // contributions of that component, pout this lane's share of the 2^DIM pressure rows (Stokes).
 // xb: wave-private LDS tile [3][LROW] for the transpose of the velocity gradient.
 // eta_tile (ETA_LDS): wave-private LDS copy [q][CPW] of the per-q viscosities of the wave's cells.
-// mid(): called once after the gather loads are issued (the block kernel parks prefetched
-// tables in LDS there, under the gather latency).
-template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, class Mid>
+// GATHER: read the cell's velocity values from global memory here; otherwise the caller has
+// filled u[] (the block kernel gathers from an LDS copy of the block's nodes).
+template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, double (*xb)[KDims<DIM>::LROW], double *G,
-                                             double *pout, const double *eta_tile, Mid &&mid) {
+                                             double *pout, const double *eta_tile, double *u) {
   constexpr int NV = KDims<DIM>::NV;
   constexpr int NP = KDims<DIM>::NP;
   constexpr int NPLP = NP / 2;  // pressure nodes per plane
@@ -149,8 +149,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
   (void)lamc; (void)ptc; (void)compc;
 
   // gather (constrained DoFs read as zero)
-  double u[NV];
-  if (HAS_U) {
+  if (HAS_U && GATHER) {
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
 #if AGMG_ABLATE & 4
@@ -166,7 +165,6 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       u[a] = ((idx >> (29 + c)) & 1u) ? 0.0 : v;
     }
   }
-  mid();
   if (HAS_U) {
     // nodal values -> values at the Gauss points, axis by axis
 #pragma unroll
@@ -372,7 +370,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cell
   const int cell = cell_l < A.n_cells ? (int)cell_l : A.n_cells - 1;
   const size_t cs = (size_t)A.cstride;
   double G[NV], pout[NP];
-  cell_compute<DIM, OP, COMP, PERQ, false>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, [] {});
+  double u[NV];
+  cell_compute<DIM, OP, COMP, PERQ, false, true>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, u);
   if (valid) {
 #pragma unroll
     for (int a = 0; a < NV; ++a)
@@ -570,6 +569,7 @@ struct BlkArgs {
   const uint4 *blk_hdr;      // per block {unique nodes, exclusive nodes, first shared slot, 0}
   const uint32_t *unodes;    // [n_blocks][max_u]: node | cmask << 29
   const uint4 *uent8;        // [n_blocks][max_u]: 8 LDS slot indices (16 bit each) per local node
+  const uint16_t *lidT;      // [3^dim][cstride]: local id (within its block) of each cell node
   double *slots_sh;
 };
 
@@ -580,11 +580,73 @@ template <int DIM> struct BlkLds {
   static constexpr int ZERO_SLOT = WAVES_PER_BLOCK * WTILE;                 // slot index of a zero triple
   static constexpr size_t slots = ((size_t)ZERO_SLOT + 4) * sizeof(double);
   static constexpr int ETA_OFF = KDims<DIM>::XB;                             // eta tile behind the exchange tile
-  static_assert(KDims<DIM>::XB + KDims<DIM>::NV * KDims<DIM>::CPW <= WTILE && KDims<DIM>::NV * 64 <= WTILE,
+  static_assert(KDims<DIM>::XB + KDims<DIM>::NV * KDims<DIM>::CPW <= WTILE && KDims<DIM>::NV * BLK_SLOT_ROW <= WTILE,
                 "exchange + eta tiles and the slot tile must fit the wave's tile");
   __host__ __device__ static size_t unodes_off(int max_u) { return slots + (size_t)max_u * 16; }
   __host__ __device__ static size_t total(int max_u) { return unodes_off(max_u) + (size_t)max_u * 4; }
 };
+
+// node-owner sums of the block kernel, specialised on the epilogue (EPI) so the item loop has no
+// switch: one thread per node of the block and all DIM components; the 8 slot entries of a node
+// are LDS byte offsets (missing ones point at the zero triple)
+template <int DIM, int EPI>
+__device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *l_ent, const uint32_t *l_unodes,
+                                              const int U, const int nex, const EpiArgs &E, double *slots_sh,
+                                              const size_t sbase) {
+  constexpr int NT = 64 * WAVES_PER_BLOCK;
+  constexpr int MAXU_PT = (KDims<DIM>::CPW * WAVES_PER_BLOCK * KDims<DIM>::NV / 2 + NT - 1) / NT;
+  uint4 e4[MAXU_PT];
+  uint32_t nd[MAXU_PT];
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int lid = min((int)threadIdx.x + i * NT, U - 1);
+    e4[i] = l_ent[lid];
+    nd[i] = l_unodes[lid];
+  }
+  double sum[MAXU_PT][DIM];
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const uint32_t ew[4] = {e4[i].x, e4[i].y, e4[i].z, e4[i].w};
+#pragma unroll
+    for (int cc = 0; cc < DIM; ++cc) sum[i][cc] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t off = (k & 1) ? (ew[k >> 1] >> 16) : (ew[k >> 1] & 0xFFFFu);
+      const double *p = reinterpret_cast<const double *>(slots_c + off);
+#pragma unroll
+      for (int cc = 0; cc < DIM; ++cc) sum[i][cc] += p[cc];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int lid = threadIdx.x + i * NT;
+    if (lid < U) {
+      if (lid < nex) {
+        const size_t g0 = (size_t)(nd[i] & NODE_MASK) * DIM;
+        double out[DIM];
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc) {
+          const bool con = (nd[i] >> (29 + cc)) & 1u;
+          const double sm = sum[i][cc];
+          const size_t t = g0 + cc;
+          if (EPI == EPI_STORE) out[cc] = con ? (E.x ? E.x[t] : 0.0) : sm;
+          else if (EPI == EPI_RESID) out[cc] = E.b[t] - (con ? (E.x ? E.x[t] : 0.0) : sm);
+          else {  // EPI_CHEB
+            const double x = E.x[t];
+            double v = fma(E.f2 * E.dinv[t], E.b[t] - (con ? x : sm), (1.0 + E.f1) * x);
+            if (E.xold) v = fma(-E.f1, E.xold[t], v);
+            out[cc] = v;
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc) E.dst[g0 + cc] = out[cc];
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc) slots_sh[sbase + (size_t)(lid - nex) * DIM + cc] = sum[i][cc];
+      }
+    }
+  }
+}
 
 template <int DIM, int OP, bool COMP, bool PERQ>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES)
@@ -593,16 +655,17 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   constexpr int BC = CPW * WAVES_PER_BLOCK, NT = 64 * WAVES_PER_BLOCK;
   constexpr int MAXU_PT = (BC * NV / 2 + NT - 1) / NT;  // nodes per thread (U <= BC*NV/2, checked on the host)
   constexpr int NETA = NV * CPW, NETA_PL = (NETA + 63) / 64;
-  constexpr bool ETA_LDS = PERQ && (OP != KOP_BT);
+  constexpr bool HAS_U = (OP != KOP_BT);
+  constexpr bool ETA_LDS = PERQ && HAS_U;
   extern __shared__ double smem[];
   char *const smem_c = reinterpret_cast<char *>(smem);
-  double *const slots = smem;                                      // [wave][a][64] + zero triple
+  double *const slots = smem;                                      // [wave][WTILE] + zero triple
   uint4 *const l_ent = reinterpret_cast<uint4 *>(smem_c + BlkLds<DIM>::slots);
   uint32_t *const l_unodes = reinterpret_cast<uint32_t *>(smem_c + BlkLds<DIM>::unodes_off(max_u));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the wave's gradient-exchange tile and its viscosity tile alias the head of its own slot
-  // tile: both are dead when the wave parks its results, and no other wave touches this slot
-  // tile before the barrier
+  // Life of the slot area: (1) copy of the source vector at the block's nodes, gathered from by
+  // all waves; (2) per wave: gradient-exchange tile + viscosity tile; (3) per wave: slot tile
+  // with the lane results.  Barriers separate (1)|(2) and (3)|node sums; (2)|(3) is wave-local.
   double *const wtile = slots + (size_t)wave * BlkLds<DIM>::WTILE;
   double (*xb)[LROW] = reinterpret_cast<double (*)[LROW]>(wtile);
   double *const eta_tile = wtile + BlkLds<DIM>::ETA_OFF;
@@ -616,8 +679,27 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   const int cell = cell_l < A.n_cells ? cell_l : A.n_cells - 1;
   const size_t cs = (size_t)A.cstride;
   AGMG_STAMP(0);
-  // prefetch, in issue order: per-q viscosities of the wave's cells, block tables (fixed stride
-  // max_u per block: no dependent address), then the cell's own loads inside cell_compute
+  // ---- all global reads of the block are issued here, coalesced.  Block tables (fixed stride
+  // max_u per block: no dependent address) go straight to LDS (LDS-DMA, no registers): wave w
+  // moves entries [i*NT + 64w, +64) of each table, i.e. exactly the ones its own lanes read back
+  const size_t mbase = (size_t)blk * max_u;
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int t = threadIdx.x + i * NT;
+    if (t < max_u) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B.unodes + mbase + t),
+                                       (__attribute__((address_space(3))) void *)(l_unodes + i * NT + wave * 64), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B.uent8 + mbase + t),
+                                       (__attribute__((address_space(3))) void *)(l_ent + i * NT + wave * 64), 16, 0, 0);
+    }
+  }
+  const uint4 hdr = B.blk_hdr[blk];
+  const int U = (int)hdr.x, nex = (int)hdr.y;
+  uint32_t lids[HAS_U ? NV : 1];
+  if (HAS_U) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) lids[a] = B.lidT[a * cs + cell];
+  }
   double m_eta[ETA_LDS ? NETA_PL : 1];
   if (ETA_LDS) {
 #pragma unroll
@@ -625,50 +707,58 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
       const int idx = lane + 64 * k;
       const int q = idx / CPW, jj = idx - q * CPW;
       const int cx = min(c0 + wave * CPW + jj, A.cstride - 1);
-      m_eta[k] = idx < NETA ? A.etaT[(size_t)q * cs + cx] : 0.0;
+      m_eta[k] = A.etaT[(size_t)min(q, NV - 1) * cs + cx];
     }
   }
-  uint4 m_ent[MAXU_PT];
-  uint32_t m_node[MAXU_PT];
-  const size_t mbase = (size_t)blk * max_u;
-#pragma unroll
-  for (int i = 0; i < MAXU_PT; ++i) {
-    const int t = threadIdx.x + i * NT;
-    if (t < max_u) {
-      m_ent[i] = B.uent8[mbase + t];
-      m_node[i] = B.unodes[mbase + t];
-    }
-  }
-  const uint4 hdr = B.blk_hdr[blk];
-  const int U = (int)hdr.x, nex = (int)hdr.y;
   if (threadIdx.x < 4) slots[BlkLds<DIM>::ZERO_SLOT + threadIdx.x] = 0.0;
+  // the tables must have landed before this wave reads its own entries (and before the block
+  // barrier publishes them to the other waves)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  double u[NV];
+  if (HAS_U) {
+    // source vector at the block's nodes -> LDS (one thread per node, constrained entries zeroed)
+    uint32_t m_node[MAXU_PT];
+    double sv[MAXU_PT][DIM];
+#pragma unroll
+    for (int i = 0; i < MAXU_PT; ++i) {   // all loads first
+      m_node[i] = l_unodes[min((int)threadIdx.x + i * NT, U - 1)];
+      const double *sp = A.src_u + (size_t)(m_node[i] & NODE_MASK) * DIM;
+#pragma unroll
+      for (int cc = 0; cc < DIM; ++cc) sv[i][cc] = sp[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU_PT; ++i) {
+      const int t = threadIdx.x + i * NT;
+      if (t < U) {
+#pragma unroll
+        for (int cc = 0; cc < DIM; ++cc) slots[t * DIM + cc] = ((m_node[i] >> (29 + cc)) & 1u) ? 0.0 : sv[i][cc];
+      }
+    }
+    AGMG_STAMP(6);
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NV; ++a) u[a] = slots[lids[a] * DIM + c];
+    __syncthreads();
+    AGMG_STAMP(7);
+  }
+  if (ETA_LDS) {
+#pragma unroll
+    for (int k = 0; k < NETA_PL; ++k) {
+      const int idx = lane + 64 * k;
+      if (idx < NETA) eta_tile[idx] = m_eta[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   {
     double G[NV], pout[NP];
     AGMG_STAMP(1);
-    cell_compute<DIM, OP, COMP, PERQ, ETA_LDS>(A, cell, c, j, lane, xb, G, pout, eta_tile, [&] {
-      if (ETA_LDS) {
-#pragma unroll
-        for (int k = 0; k < NETA_PL; ++k) {
-          const int idx = lane + 64 * k;
-          if (idx < NETA) eta_tile[idx] = m_eta[k];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MAXU_PT; ++i) {
-        const int t = threadIdx.x + i * NT;
-        if (t < max_u) {
-          l_ent[t] = m_ent[i];
-          l_unodes[t] = m_node[i];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    });
+    cell_compute<DIM, OP, COMP, PERQ, ETA_LDS, false>(A, cell, c, j, lane, xb, G, pout, eta_tile, u);
     AGMG_STAMP(2);
     double *my = wtile + lane;
 #pragma unroll
-    for (int a = 0; a < NV; ++a) my[a * 64] = G[a];
+    for (int a = 0; a < NV; ++a) my[a * BLK_SLOT_ROW] = G[a];
     if (OP == KOP_STOKES && lane_ok && cell_l < A.n_cells) {
 #pragma unroll
       for (int bb = 0; bb < NP; ++bb) A.slots_p[((size_t)bb * cs + cell) * DIM + c] = pout[bb];
@@ -680,46 +770,10 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
 #if AGMG_ABLATE & 128
   if (slots[threadIdx.x] != 12345.678) return;
 #endif
-  // node-owner sum out of the slot tile: one thread per node of the block, all DIM components;
-  // 8 slots per node in a fixed order (missing ones point at the zero triple)
   const size_t sbase = (size_t)hdr.z * DIM;
-#pragma unroll
-  for (int i = 0; i < MAXU_PT; ++i) {
-    const int lid = threadIdx.x + i * NT;
-    if (lid < U) {
-      const uint4 e4 = l_ent[lid];
-      const uint32_t ew[4] = {e4.x, e4.y, e4.z, e4.w};
-      double sum[DIM];
-#pragma unroll
-      for (int cc = 0; cc < DIM; ++cc) sum[cc] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t ent = (k & 1) ? (ew[k >> 1] >> 16) : (ew[k >> 1] & 0xFFFFu);
-#pragma unroll
-        for (int cc = 0; cc < DIM; ++cc) sum[cc] += slots[ent + cc];
-      }
-      if (lid < nex) {
-        const uint32_t nd = l_unodes[lid];
-        const size_t g0 = (size_t)(nd & NODE_MASK) * DIM;
-#pragma unroll
-        for (int cc = 0; cc < DIM; ++cc) {
-          const bool con = (nd >> (29 + cc)) & 1u;
-          double out;
-#if AGMG_ABLATE & 512
-          if (sum[cc] == 12345.678)
-#endif
-          if (epi_value(E, g0 + cc, sum[cc], con, out)) E.dst[g0 + cc] = out;
-        }
-      } else {
-#pragma unroll
-        for (int cc = 0; cc < DIM; ++cc)
-#if AGMG_ABLATE & 512
-          if (sum[cc] == 12345.678)
-#endif
-          B.slots_sh[sbase + (size_t)(lid - nex) * DIM + cc] = sum[cc];
-      }
-    }
-  }
+  if (E.epi == EPI_CHEB) blk_node_sums<DIM, EPI_CHEB>(smem_c, l_ent, l_unodes, U, nex, E, B.slots_sh, sbase);
+  else if (E.epi == EPI_RESID) blk_node_sums<DIM, EPI_RESID>(smem_c, l_ent, l_unodes, U, nex, E, B.slots_sh, sbase);
+  else blk_node_sums<DIM, EPI_STORE>(smem_c, l_ent, l_unodes, U, nex, E, B.slots_sh, sbase);
   AGMG_STAMP(5);
 }
 
@@ -890,7 +944,7 @@ int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int 
 
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks) {
-  if (!use_blocks || !L.bt.built) {
+  if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB)) {
     const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
     if (rc) return rc;
     return launch_pull_v(s, L, slots_u, eu);
@@ -904,7 +958,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
 #if AGMG_ABLATE & 1024
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)4000000 * 8 * 8);
 #endif
-  BlkArgs b{dbg_buf, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), slots_u};
+  BlkArgs b{dbg_buf, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), bt.lidT, slots_u};
   const bool perq = cd.nqv > 1;
   const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
   const int lds = bt.max_unodes;
@@ -929,8 +983,14 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
     double d[5] = {0, 0, 0, 0, 0};
     for (size_t w = 0; w < nw; ++w)
       for (int k = 0; k < 5; ++k) d[k] += (double)(h[w * 8 + k + 1] - h[w * 8 + k]);
-    fprintf(stderr, "stamps (mean cycles/wave): meta-issue %.0f | cell_compute %.0f | park+meta->LDS %.0f | barrier %.0f | pull %.0f\n",
-            d[0] / nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw);
+    double p1 = 0, p2 = 0, p3 = 0;
+    for (size_t w = 0; w < nw; ++w) {
+      p1 += (double)(h[w * 8 + 6] - h[w * 8 + 0]);
+      p2 += (double)(h[w * 8 + 7] - h[w * 8 + 6]);
+      p3 += (double)(h[w * 8 + 1] - h[w * 8 + 7]);
+    }
+    fprintf(stderr, "stamps (mean cycles/wave): prologue %.0f [issue+src->LDS %.0f | barrier+gather+barrier %.0f | park %.0f] | cell_compute %.0f | park %.0f | barrier %.0f | pull %.0f\n",
+            d[0] / nw, p1 / nw, p2 / nw, p3 / nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw);
   }
 #endif
   if (bt.n_shared > 0) {
