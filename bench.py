@@ -52,33 +52,19 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from aspect_amd.parallel import Ranks
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    ranks = Ranks(backend="nccl", device=dev)
+    rank, world = ranks.rank, ranks.world
 
     from aspect_amd import capi, cases
     lib = capi.load()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
 
     # ---------------------------------------------------------------- workload (configs[1])
     prob = cases.convection_box(3, args.refinement).build()
@@ -113,7 +99,7 @@ def main():
     t_A = solver.bench_vmult(capi.OP_A, capi.ACTIVE, 100)
     t_S = solver.bench_vmult(capi.OP_STOKES, capi.ACTIVE, 100)
     bytes_A = fin.n_cells * algorithmic_bytes_per_cell(nqv)
-    roof = {"kernel": "A-block vmult = k_cells<A> + k_pull (ABlockOperator::vmult)", "bound": "hbm",
+    roof = {"kernel": "A-block vmult = k_cells_blk<A> + k_fix (ABlockOperator::vmult)", "bound": "hbm",
             "achieved": bytes_A / t_A / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_A / t_A / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "us_per_launch": 1e6 * t_A, "gdofs": nu / t_A / 1e9,
@@ -173,8 +159,7 @@ def main():
                            "parallelism": "1 rank" if world == 1 else f"{world} independent subdomain replicas (no ghost exchange yet)"},
                 "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, **extra}
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
