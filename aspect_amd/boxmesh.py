@@ -17,7 +17,11 @@ of uniformly refined levels:
   Dirichlet row: zero velocity -> all bits, axis-aligned no-normal-flux ->
   the normal component only; local_smoothing.cc:1597-1620, 1675-1698,
   1794-1821);
-* Cartesian geometry (MappingCartesian, core.cc:118-119): cell extents.
+* Cartesian geometry (MappingCartesian, core.cc:118-119): cell extents; or,
+  with a ``deform`` map, general geometry: inverse Jacobians and JxW at the
+  Gauss points of the isoparametric Q2 mapping through the displaced nodes
+  (the tables MatrixFree's MappingInfo holds for a MappingQ mesh,
+  core.cc:120-121).
 
 Element conventions follow SURVEY.md A.1: lexicographic cell-local DoF order,
 Gauss-3 quadrature per direction for every operator.
@@ -75,8 +79,9 @@ BC_NONE, BC_ZERO, BC_TANGENTIAL = 0, 1, 2
 class Level:
     """Flat tables of one mesh level (what ``agmg_level_desc`` carries)."""
 
-    def __init__(self, dim, extents, reps, l, bc):
+    def __init__(self, dim, extents, reps, l, bc, deform=None):
         self.dim = dim
+        self.deform = deform
         self.level = l
         self.extents = np.asarray(extents, dtype=np.float64)
         self.reps = np.asarray(reps, dtype=np.int64)
@@ -104,6 +109,25 @@ class Level:
         self.cmask_v = self._constraint_mask(bc)
         self.cmask_p = np.zeros(self.n_nodes_p, dtype=np.uint8)
         self.cell_h = np.tile(self.h, (self.n_cells, 1))
+        self.general = deform is not None
+        if self.general:
+            self._general_geometry()
+
+    def _general_geometry(self):
+        """inv_jacobian [cell][q][e][d] = d xi_e / d x_d and jxw [cell][q] of the Q2 mapping."""
+        dim = self.dim
+        X = self.node_coords_v()[self.cell_nodes_v.astype(np.int64)]     # [cell][i][d]
+        self.inv_jacobian = np.zeros((self.n_cells, 3 ** dim, dim, dim))
+        J = np.zeros((self.n_cells, 3 ** dim, dim, dim))                 # [cell][q][d][e] = d x_d / d xi_e
+        for e in range(dim):
+            dN = tensor_shape([D2 if k == e else N2 for k in range(dim)])   # [q][i]
+            J[:, :, :, e] = np.einsum("qi,cid->cqd", dN, X)
+        det = np.linalg.det(J)
+        if not np.all(det > 0):
+            raise ValueError("deformation inverts cells")
+        self.inv_jacobian = np.linalg.inv(J)
+        W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1)
+        self.jxw = det * W[None, :]
 
     # -- tables -----------------------------------------------------------
     def _cell_nodes(self, n1, stride, nd):
@@ -119,11 +143,13 @@ class Level:
 
     def node_coords_v(self):
         idx = np.indices(tuple(self.nvd[::-1])).reshape(self.dim, -1)[::-1]
-        return np.stack([idx[d] * (self.h[d] / 2) for d in range(self.dim)], axis=1)
+        x = np.stack([idx[d] * (self.h[d] / 2) for d in range(self.dim)], axis=1)
+        return self.deform(x) if self.deform is not None else x
 
     def node_coords_p(self):
         idx = np.indices(tuple(self.npd[::-1])).reshape(self.dim, -1)[::-1]
-        return np.stack([idx[d] * self.h[d] for d in range(self.dim)], axis=1)
+        x = np.stack([idx[d] * self.h[d] for d in range(self.dim)], axis=1)
+        return self.deform(x) if self.deform is not None else x
 
     def _constraint_mask(self, bc):
         """bc: list of 2*dim codes in deal.II box boundary-id order
@@ -145,6 +171,9 @@ class Level:
     def qpoint_coords(self):
         """Physical coordinates of the 3^dim Gauss points, [n_cells][nq][dim]."""
         dim = self.dim
+        if self.general:
+            X = self.node_coords_v()[self.cell_nodes_v.astype(np.int64)]
+            return np.einsum("qi,cid->cqd", tensor_shape([N2] * dim), X)
         q = np.indices((3,) * dim).reshape(dim, -1)[::-1]
         out = np.zeros((self.n_cells, 3 ** dim, dim))
         for d in range(dim):
@@ -171,14 +200,14 @@ class Level:
 class BoxHierarchy:
     """Levels 0..refinement of a box; level ``refinement`` is also the active mesh."""
 
-    def __init__(self, dim, refinement, extents=None, reps=None, bc=None, only_finest=False):
+    def __init__(self, dim, refinement, extents=None, reps=None, bc=None, only_finest=False, deform=None):
         self.dim = dim
         extents = [1.0] * dim if extents is None else extents
         reps = [1] * dim if reps is None else reps
         bc = [BC_TANGENTIAL] * (2 * dim) if bc is None else bc
         self.bc = list(bc)
         first = refinement if only_finest else 0
-        self.levels = [Level(dim, extents, reps, l, bc) for l in range(first, refinement + 1)]
+        self.levels = [Level(dim, extents, reps, l, bc, deform) for l in range(first, refinement + 1)]
 
     @property
     def finest(self):
@@ -261,6 +290,8 @@ def viscosity_tables(hier, eta_func, averaging):
         # (utilities.cc:2697-2770), then child means.
         W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1)
         cur = eta_q @ W
+        if fin.general:
+            cur = (eta_q * fin.jxw).sum(axis=1) / fin.jxw.sum(axis=1)
         levels = [None] * nL
         levels[nL - 1] = cur[:, None].copy()
         for l in range(nL - 2, -1, -1):
@@ -290,9 +321,12 @@ def assemble_rhs_u(level, force_func):
     dim = level.dim
     xq = level.qpoint_coords()
     f = force_func(xq.reshape(-1, dim)).reshape(level.n_cells, -1, dim)
-    W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(level.h)
     Nq = tensor_shape([N2] * dim)                      # [q][i]
-    loc = np.einsum("qi,q,cqd->cid", Nq, W, f)         # [cell][i][d]
+    if level.general:
+        loc = np.einsum("qi,cq,cqd->cid", Nq, level.jxw, f)
+    else:
+        W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(level.h)
+        loc = np.einsum("qi,q,cqd->cid", Nq, W, f)     # [cell][i][d]
     out = np.zeros((level.n_nodes_v, dim))
     np.add.at(out, level.cell_nodes_v.astype(np.int64), loc)
     out = out.reshape(-1)

@@ -224,9 +224,17 @@ class Solver:
         d.cell_nodes_p = _ptr(cnp, C.c_uint32)
         d.constrained_v = _ptr(cmv, C.c_uint8)
         d.constrained_p = _ptr(cmp_, C.c_uint8)
-        d.geometry_kind = GEOM_CARTESIAN
-        d.cell_h = _ptr(ch, C.c_double)
         keep = [cnv, cnp, cmv, cmp_, ch]
+        if getattr(lev, "general", False):
+            ij = np.ascontiguousarray(lev.inv_jacobian, dtype=np.float64)
+            jw = np.ascontiguousarray(lev.jxw, dtype=np.float64)
+            d.geometry_kind = GEOM_GENERAL
+            d.inv_jacobian = _ptr(ij, C.c_double)
+            d.jxw = _ptr(jw, C.c_double)
+            keep += [ij, jw]
+        else:
+            d.geometry_kind = GEOM_CARTESIAN
+            d.cell_h = _ptr(ch, C.c_double)
         if l > 0 and lev.level > 0:
             nch = 1 << lev.dim
             par = (np.arange(lev.n_cells, dtype=np.int32) // nch).astype(np.int32)

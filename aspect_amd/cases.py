@@ -56,10 +56,12 @@ class StokesProblem:
     krylov: str = "gmres"
     idr_s: int = 2
     initial_pressure: callable = None   # x -> p0 (unscaled), static pressure guess
+    deform: callable = None             # x -> x' smooth map of the box (general / MappingQ geometry)
     hier: bm.BoxHierarchy = field(default=None, repr=False)
 
     def build(self):
-        self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc)
+        self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
+                                    deform=self.deform)
         self.eta_active, self.eta_levels, self.eta_min, self.eta_max = \
             bm.viscosity_tables(self.hier, self.eta, self.averaging)
         fin = self.hier.finest
@@ -74,7 +76,7 @@ class StokesProblem:
     def build_single_level(self):
         """Only the active mesh (operator benchmarks on big levels: no hierarchy, no RHS)."""
         self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    only_finest=True)
+                                    only_finest=True, deform=self.deform)
         fin = self.hier.finest
         nq = 3 ** self.dim
         if self.averaging == bm.AVG_HARMONIC:
@@ -182,3 +184,42 @@ def stokes_sinker_box(refinement):
         bc=[bm.BC_TANGENTIAL] * 6, eta=lambda x: np.full(x.shape[0], 1e22),
         force=force, averaging=bm.AVG_PROJECT_Q1, pressure_scaling=1e22 / (0.01 * L),
         extents=[L, L, L], initial_pressure=p_static)
+
+
+def deformed_sinker_box(dim, refinement, amplitude=0.06, ratio=1e3, averaging=bm.AVG_NONE, **kw):
+    """Curved-cell stand-in for the MappingQ meshes of config 4 (spherical shell,
+    SURVEY.md 8 config 4): the unit box under a smooth interior displacement that
+    vanishes on the boundary (so zero-velocity walls stay exact), every cell with a
+    full, q-point-dependent Jacobian; sinker viscosity/density as in nsinker."""
+    sr = np.sqrt(ratio)
+    centers = NSINKER_CENTERS[:4, :dim]
+
+    def deform(x):
+        bump = np.prod(np.sin(np.pi * x), axis=1)
+        y = x.copy()
+        for d in range(dim):
+            y[:, d] += amplitude * bump * np.cos(2.0 * np.pi * x[:, (d + 1) % dim] + 0.7 * d)
+        return y
+
+    def chi(x):
+        c = np.ones(x.shape[0])
+        for s in range(centers.shape[0]):
+            r = np.sqrt(((x - centers[s][None, :]) ** 2).sum(axis=1))
+            t = np.maximum(0.0, r - 0.05)
+            c *= 1.0 - np.exp(-200.0 * t * t)
+        return c
+
+    def eta(x):
+        return (sr - 1.0 / sr) * (1.0 - chi(x)) + 1.0 / sr
+
+    def force(x):
+        f = np.zeros_like(x)
+        f[:, -1] = -10.0 * (1.0 - chi(x))
+        return f
+
+    args = dict(tol=1e-6, n_cheap=200, n_expensive=0)
+    args.update(kw)
+    return StokesProblem(
+        name=f"deformed_sinker_{dim}d_r{refinement}", dim=dim, refinement=refinement,
+        bc=[bm.BC_ZERO] * (2 * dim), eta=eta, force=force, averaging=averaging,
+        pressure_scaling=1.0, deform=deform, **args)

@@ -83,7 +83,8 @@ __host__ __device__ constexpr double dcol(int q, int i) {  // collocation deriva
 struct CellArgs {
   int n_cells, cstride;
   const uint32_t *cnvT, *cnpT;
-  const double *hT;
+  const double *hT;                  // Cartesian: [DIM][cstride]
+  const double *invJT, *jxwT;        // general: [q][DIM*DIM][cstride], [q][cstride]
   const double *etaT;
   double lambda;
   const double *src_u, *src_p;
@@ -118,7 +119,8 @@ template <int DIM> struct KDims {
 // eta_tile (ETA_LDS): wave-private LDS copy [q][CPW] of the per-q viscosities of the wave's cells.
 // GATHER: read the cell's velocity values from global memory here; otherwise the caller has
 // filled u[] (the block kernel gathers from an LDS copy of the block's nodes).
-template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER>
+// GEN: general (MappingQ) geometry: full inverse Jacobian and JxW per q-point instead of cell extents.
+template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, double (*xb)[KDims<DIM>::LROW], double *G,
                                              double *pout, const double *eta_tile, double *u) {
@@ -133,10 +135,14 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
   double ih[DIM], det = 1.0;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) {
-    const double h = A.hT[d * cs + cell];
+    const double h = GEN ? 1.0 : A.hT[d * cs + cell];
     det *= h;
     ih[d] = INV_S / h;
   }
+  double sel[DIM];   // 1 on this lane's own component
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) sel[d] = (d == c) ? 1.0 : 0.0;
+  (void)sel;
   const double eta_c = PERQ ? 1.0 : A.etaT[cell];
   double cw[DIM], lamc[DIM], ptc[DIM], compc[DIM];
 #pragma unroll
@@ -210,6 +216,16 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
     const int base = 3 * L;
     double d[DIM][3];
     double pq[3], pt[3];
+    double Ji[GEN ? 3 : 1][DIM][DIM];   // inverse Jacobians of the line's q-points (general geometry)
+    if (GEN && !HAS_U) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int e = 0; e < DIM; ++e)
+#pragma unroll
+          for (int dd = 0; dd < DIM; ++dd)
+            Ji[x][e][dd] = A.invJT[((size_t)(base + x) * (DIM * DIM) + e * DIM + dd) * cs + cell];
+    }
     if (HAS_P) {
       // Q1 values on this line
       double t0, t1;
@@ -243,12 +259,28 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       }
       // physical gradient row of this lane's component -> LDS
 #pragma unroll
-      for (int x = 0; x < 3; ++x)
+      for (int x = 0; x < 3; ++x) {
+        if (GEN) {
+          double g[DIM];
 #pragma unroll
-        for (int dd = 0; dd < DIM; ++dd) {
-          d[dd][x] *= ih[dd];
-          xb[x][lane * DIM + dd] = d[dd][x];
+          for (int dd = 0; dd < DIM; ++dd) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < DIM; ++e) {
+              Ji[x][e][dd] = A.invJT[((size_t)(base + x) * (DIM * DIM) + e * DIM + dd) * cs + cell];
+              acc = fma(d[e][x], Ji[x][e][dd], acc);
+            }
+            g[dd] = INV_S * acc;
+          }
+#pragma unroll
+          for (int dd = 0; dd < DIM; ++dd) d[dd][x] = g[dd];
+        } else {
+#pragma unroll
+          for (int dd = 0; dd < DIM; ++dd) d[dd][x] *= ih[dd];
         }
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) xb[x][lane * DIM + dd] = d[dd][x];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -256,34 +288,76 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
       const double wq = (DIM == 3) ? wq1(x) * wq1(qy) * wq1(qz) : wq1(x) * wq1(qy);
-      double f = wq;
+      double etav = 1.0;
 #if !(AGMG_ABLATE & 8)
-      if (PERQ) f *= ETA_LDS ? eta_tile[(base + x) * KDims<DIM>::CPW + j] : A.etaT[(size_t)(base + x) * cs + cell];
+      if (PERQ) etav = ETA_LDS ? eta_tile[(base + x) * KDims<DIM>::CPW + j] : A.etaT[(size_t)(base + x) * cs + cell];
 #endif
+      const double f = wq * etav;
       if (HAS_U) {
         // column c of the velocity gradient: du_dd/dx_c lives in the lane of component dd
         double t[DIM];
 #pragma unroll
         for (int dd = 0; dd < DIM; ++dd) t[dd] = d[dd][x] + xb[x][(j * DIM + dd) * DIM + c];
-        double fdiv = 0.0;
+        double fdiv = 0.0, div = 0.0;
         if (COMP) {
-          double div = 0.0;
 #pragma unroll
           for (int e = 0; e < DIM; ++e) div += xb[x][(j * DIM + e) * DIM + e];
           fdiv = f * div;
         }
+        (void)fdiv;
+        if (GEN) {
+          // JxW carries the quadrature weight
+          const double jxw = A.jxwT[(size_t)(base + x) * cs + cell];
+          const double etaq = eta_c * etav;
+          double tau[DIM];
 #pragma unroll
-        for (int dd = 0; dd < DIM; ++dd) {
-          double F = (cw[dd] * f) * t[dd];
-          if (COMP) F = fma(-compc[dd], fdiv, F);
-          if (HAS_P) F = fma(-lamc[dd], wq * pq[x], F);
-          d[dd][x] = F;
+          for (int dd = 0; dd < DIM; ++dd) {
+            tau[dd] = etaq * t[dd];
+            if (COMP) tau[dd] = fma(-sel[dd] * (2.0 / 3.0) * etaq, div, tau[dd]);
+            if (HAS_P) tau[dd] = fma(-sel[dd] * A.lambda, pq[x], tau[dd]);
+          }
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) {
+            double acc = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < DIM; ++dd) {
+              // Stokes runs out of registers holding the line's Jacobians across the exchange: reload (L1 hit)
+              const double jv = (OP == KOP_STOKES && DIM == 3)
+                                    ? A.invJT[((size_t)(base + x) * (DIM * DIM) + e * DIM + dd) * cs + cell]
+                                    : Ji[x][e][dd];
+              acc = fma(jv, tau[dd], acc);
+            }
+            d[e][x] = (jxw * INV_S) * acc;
+          }
+          if (OP == KOP_STOKES) {
+            double s = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < DIM; ++dd) s = fma(sel[dd], t[dd], s);
+            pt[x] = (-0.5 * A.lambda * jxw) * s;
+          }
+        } else {
+#pragma unroll
+          for (int dd = 0; dd < DIM; ++dd) {
+            double F = (cw[dd] * f) * t[dd];
+            if (COMP) F = fma(-compc[dd], fdiv, F);
+            if (HAS_P) F = fma(-lamc[dd], wq * pq[x], F);
+            d[dd][x] = F;
+          }
+          if (OP == KOP_STOKES) {
+            double s = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < DIM; ++dd) s = fma(ptc[dd], t[dd], s);
+            pt[x] = wq * s;
+          }
         }
-        if (OP == KOP_STOKES) {
-          double s = 0.0;
+      } else if (GEN) {
+        const double jxw = A.jxwT[(size_t)(base + x) * cs + cell];
 #pragma unroll
-          for (int dd = 0; dd < DIM; ++dd) s = fma(ptc[dd], t[dd], s);
-          pt[x] = wq * s;
+        for (int e = 0; e < DIM; ++e) {
+          double acc = 0.0;
+#pragma unroll
+          for (int dd = 0; dd < DIM; ++dd) acc = fma(Ji[x][e][dd], sel[dd], acc);
+          d[e][x] = (-A.lambda * jxw * INV_S) * pq[x] * acc;
         }
       } else {
 #pragma unroll
@@ -356,7 +430,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 }
 
 // slot variant: every cell writes its contributions to slots [local dof][cell][component]
-template <int DIM, int OP, bool COMP, bool PERQ>
+template <int DIM, int OP, bool COMP, bool PERQ, bool GEN>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cells(const CellArgs A) {
   constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
   __shared__ double xbuf[WAVES_PER_BLOCK][3][LROW];
@@ -371,7 +445,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cell
   const size_t cs = (size_t)A.cstride;
   double G[NV], pout[NP];
   double u[NV];
-  cell_compute<DIM, OP, COMP, PERQ, false, true>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, u);
+  cell_compute<DIM, OP, COMP, PERQ, false, true, GEN>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, u);
   if (valid) {
 #pragma unroll
     for (int a = 0; a < NV; ++a)
@@ -387,7 +461,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cell
 }
 
 // ---- pressure mass matrix: one lane per cell ---------------------------------------------
-template <int DIM, bool PERQ>
+template <int DIM, bool PERQ, bool GEN>
 __global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
   constexpr int NP = (DIM == 3) ? 8 : 4;
   constexpr int NQ = (DIM == 3) ? 27 : 9;
@@ -396,7 +470,7 @@ __global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
   const size_t cs = (size_t)A.cstride;
   double det = 1.0;
 #pragma unroll
-  for (int d = 0; d < DIM; ++d) det *= A.hT[d * cs + cell];
+  for (int d = 0; d < DIM; ++d) det *= GEN ? 1.0 : A.hT[d * cs + cell];
   const double scale = A.lambda * A.lambda * det;
   double pin[NP];
 #pragma unroll
@@ -421,7 +495,7 @@ __global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
     const double wq = wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
     // per-lane division as in matrix_free_operators.cc:556-563
     const double ie = PERQ ? 1.0 / A.etaT[(size_t)q * cs + cell] : inv_eta_c;
-    v *= wq * scale * ie;
+    v *= (GEN ? A.jxwT[(size_t)q * cs + cell] : wq) * scale * ie;
 #pragma unroll
     for (int b = 0; b < NP; ++b) {
       const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
@@ -436,7 +510,7 @@ __global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
 // velocity: lane per (cell, local node); entry (a, c) = sum_q JxW eta (|grad phi|^2 + (d_c phi)^2
 //           [- 2/3 (d_c phi)^2 if compressible])
 template <int DIM>
-__global__ void __launch_bounds__(256) k_diag_v(const CellArgs A, int comp, int nqv) {
+__global__ void __launch_bounds__(256) k_diag_v(const CellArgs A, int comp, int nqv, int gen) {
   constexpr int NV = (DIM == 3) ? 27 : 9;
   constexpr int NQ = NV;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -444,7 +518,8 @@ __global__ void __launch_bounds__(256) k_diag_v(const CellArgs A, int comp, int 
   if (cell >= A.n_cells) return;
   const size_t cs = (size_t)A.cstride;
   double h[3] = {1, 1, 1}, det = 1.0;
-  for (int d = 0; d < DIM; ++d) { h[d] = A.hT[d * cs + cell]; det *= h[d]; }
+  if (!gen)
+    for (int d = 0; d < DIM; ++d) { h[d] = A.hT[d * cs + cell]; det *= h[d]; }
   const int ai[3] = {a % 3, (a / 3) % 3, a / 9};
   double acc[3] = {0, 0, 0};
   for (int q = 0; q < NQ; ++q) {
@@ -455,6 +530,13 @@ __global__ void __launch_bounds__(256) k_diag_v(const CellArgs A, int comp, int 
       for (int d = 0; d < DIM; ++d) v *= (d == e) ? d2(qi[d], ai[d]) : n2(qi[d], ai[d]);
       g[e] = v / h[e];
       wq *= wq1(qi[e]);
+    }
+    if (gen) {  // reference gradient -> physical gradient, JxW from the table
+      double gp[3] = {0, 0, 0};
+      for (int dd = 0; dd < DIM; ++dd)
+        for (int e = 0; e < DIM; ++e) gp[dd] += g[e] * A.invJT[((size_t)q * (DIM * DIM) + e * DIM + dd) * cs + cell];
+      for (int dd = 0; dd < DIM; ++dd) g[dd] = gp[dd];
+      wq = A.jxwT[(size_t)q * cs + cell];
     }
     const double eta = A.etaT[(nqv == 1 ? 0 : (size_t)q * cs) + cell];
     double n2g = 0.0;
@@ -469,7 +551,7 @@ __global__ void __launch_bounds__(256) k_diag_v(const CellArgs A, int comp, int 
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(256) k_diag_p(const CellArgs A, int nqv) {
+__global__ void __launch_bounds__(256) k_diag_p(const CellArgs A, int nqv, int gen) {
   constexpr int NP = (DIM == 3) ? 8 : 4;
   constexpr int NQ = (DIM == 3) ? 27 : 9;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -477,12 +559,13 @@ __global__ void __launch_bounds__(256) k_diag_p(const CellArgs A, int nqv) {
   if (cell >= A.n_cells) return;
   const size_t cs = (size_t)A.cstride;
   double det = 1.0;
-  for (int d = 0; d < DIM; ++d) det *= A.hT[d * cs + cell];
+  if (!gen)
+    for (int d = 0; d < DIM; ++d) det *= A.hT[d * cs + cell];
   double acc = 0.0;
   for (int q = 0; q < NQ; ++q) {
     const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
     const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
-    const double wq = wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
+    const double wq = gen ? A.jxwT[(size_t)q * cs + cell] : wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
     const double eta = A.etaT[(nqv == 1 ? 0 : (size_t)q * cs) + cell];
     acc += wq * det * A.lambda * A.lambda / eta * w * w;
   }
@@ -648,7 +731,7 @@ __device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *
   }
 }
 
-template <int DIM, int OP, bool COMP, bool PERQ>
+template <int DIM, int OP, bool COMP, bool PERQ, bool GEN>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES)
 k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u) {
   constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
@@ -754,7 +837,7 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   {
     double G[NV], pout[NP];
     AGMG_STAMP(1);
-    cell_compute<DIM, OP, COMP, PERQ, ETA_LDS, false>(A, cell, c, j, lane, xb, G, pout, eta_tile, u);
+    cell_compute<DIM, OP, COMP, PERQ, ETA_LDS, false, GEN>(A, cell, c, j, lane, xb, G, pout, eta_tile, u);
     AGMG_STAMP(2);
     double *my = wtile + lane;
 #pragma unroll
@@ -814,6 +897,8 @@ CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, 
   a.cnvT = L.cnvT;
   a.cnpT = L.cnpT;
   a.hT = L.cell_hT;
+  a.invJT = L.invJT;
+  a.jxwT = L.jxwT;
   a.etaT = cd.etaT;
   a.lambda = cd.lambda;
   a.src_u = su;
@@ -823,20 +908,26 @@ CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, 
   return a;
 }
 
-template <int DIM, int OP>
+template <int DIM, int OP, bool GEN>
 void launch_cells_t(hipStream_t s, const CellArgs &a, bool comp, bool perq) {
   const int cpb = (64 / DIM) * WAVES_PER_BLOCK;
   const dim3 grid((a.n_cells + cpb - 1) / cpb), block(64 * WAVES_PER_BLOCK);
   if (comp) {
-    if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, true, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_cells<DIM, OP, true, false>), grid, block, 0, s, a);
+    if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, true, true, GEN>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_cells<DIM, OP, true, false, GEN>), grid, block, 0, s, a);
   } else {
-    if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_cells<DIM, OP, false, false>), grid, block, 0, s, a);
+    if (perq) hipLaunchKernelGGL((k_cells<DIM, OP, false, true, GEN>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_cells<DIM, OP, false, false, GEN>), grid, block, 0, s, a);
   }
 }
+template <int DIM, bool GEN>
+void launch_cells_op(hipStream_t s, const CellArgs &a, int which, bool comp, bool perq) {
+  if (which == AGMG_OP_A) launch_cells_t<DIM, KOP_A, GEN>(s, a, comp, perq);
+  else if (which == AGMG_OP_STOKES) launch_cells_t<DIM, KOP_STOKES, GEN>(s, a, comp, perq);
+  else launch_cells_t<DIM, KOP_BT, GEN>(s, a, false, false);
+}
 
-template <int DIM, int OP>
+template <int DIM, int OP, bool GEN>
 int launch_blk_t(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiArgs &e, int n_blocks, int max_u,
                  bool comp, bool perq) {
   const size_t lds = BlkLds<DIM>::total(max_u);
@@ -845,74 +936,80 @@ int launch_blk_t(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiAr
   do {                                                                                                     \
     static size_t lds_set = 0;                                                                             \
     if (lds > lds_set) {                                                                                   \
-      AGMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_blk<DIM, OP, C, Q>),      \
+      AGMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_blk<DIM, OP, C, Q, GEN>),      \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
       lds_set = lds;                                                                                       \
     }                                                                                                      \
-    hipLaunchKernelGGL((k_cells_blk<DIM, OP, C, Q>), grid, block, lds, s, a, b, e, max_u);                        \
+    hipLaunchKernelGGL((k_cells_blk<DIM, OP, C, Q, GEN>), grid, block, lds, s, a, b, e, max_u);                        \
   } while (0)
   if (comp) { if (perq) AGMG_BLK_LAUNCH(true, true); else AGMG_BLK_LAUNCH(true, false); }
   else { if (perq) AGMG_BLK_LAUNCH(false, true); else AGMG_BLK_LAUNCH(false, false); }
 #undef AGMG_BLK_LAUNCH
   return 0;
 }
+template <int DIM, bool GEN>
+int launch_blk_op(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiArgs &e, int n_blocks, int max_u,
+                  int which, bool comp, bool perq) {
+  if (which == AGMG_OP_A) return launch_blk_t<DIM, KOP_A, GEN>(s, a, b, e, n_blocks, max_u, comp, perq);
+  if (which == AGMG_OP_STOKES) return launch_blk_t<DIM, KOP_STOKES, GEN>(s, a, b, e, n_blocks, max_u, comp, perq);
+  return launch_blk_t<DIM, KOP_BT, GEN>(s, a, b, e, n_blocks, max_u, false, false);
+}
 
 }  // namespace
 
 int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
                     const double *src_p, double *slots_u, double *slots_p) {
-  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
   const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
   const bool perq = cd.nqv > 1;
   // the compressible term only exists where the velocity is read (A, Stokes)
   const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
+  const bool gen = L.geom == AGMG_GEOM_GENERAL;
   if (L.dim == 3) {
-    if (which == AGMG_OP_A) launch_cells_t<3, KOP_A>(s, a, comp, perq);
-    else if (which == AGMG_OP_STOKES) launch_cells_t<3, KOP_STOKES>(s, a, comp, perq);
-    else launch_cells_t<3, KOP_BT>(s, a, false, false);
+    if (gen) launch_cells_op<3, true>(s, a, which, comp, perq);
+    else launch_cells_op<3, false>(s, a, which, comp, perq);
   } else {
-    if (which == AGMG_OP_A) launch_cells_t<2, KOP_A>(s, a, comp, perq);
-    else if (which == AGMG_OP_STOKES) launch_cells_t<2, KOP_STOKES>(s, a, comp, perq);
-    else launch_cells_t<2, KOP_BT>(s, a, false, false);
+    if (gen) launch_cells_op<2, true>(s, a, which, comp, perq);
+    else launch_cells_op<2, false>(s, a, which, comp, perq);
   }
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, double *slots_p) {
-  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
   const CellArgs a = make_args(L, cd, nullptr, src_p, nullptr, slots_p);
   const dim3 grid((L.n_cells + 255) / 256), block(256);
   const bool perq = cd.nqv > 1;
-  if (L.dim == 3) {
-    if (perq) hipLaunchKernelGGL((k_mass<3, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_mass<3, false>), grid, block, 0, s, a);
-  } else {
-    if (perq) hipLaunchKernelGGL((k_mass<2, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_mass<2, false>), grid, block, 0, s, a);
-  }
+  const bool gen = L.geom == AGMG_GEOM_GENERAL;
+#define AGMG_MASS_LAUNCH(D, G)                                                        \
+  do {                                                                                \
+    if (perq) hipLaunchKernelGGL((k_mass<D, true, G>), grid, block, 0, s, a);         \
+    else hipLaunchKernelGGL((k_mass<D, false, G>), grid, block, 0, s, a);             \
+  } while (0)
+  if (L.dim == 3) { if (gen) AGMG_MASS_LAUNCH(3, true); else AGMG_MASS_LAUNCH(3, false); }
+  else { if (gen) AGMG_MASS_LAUNCH(2, true); else AGMG_MASS_LAUNCH(2, false); }
+#undef AGMG_MASS_LAUNCH
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u, double *slots_p) {
-  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
   const CellArgs a = make_args(L, cd, nullptr, nullptr, slots_u, slots_p);
   const int nv = L.dim == 3 ? 27 : 9, np = L.dim == 3 ? 8 : 4;
+  const int gen = L.geom == AGMG_GEOM_GENERAL;
   const dim3 block(256);
   const dim3 gv((unsigned)(((long)L.n_cells * nv + 255) / 256)), gp((unsigned)(((long)L.n_cells * np + 255) / 256));
   if (L.dim == 3) {
-    hipLaunchKernelGGL((k_diag_v<3>), gv, block, 0, s, a, cd.is_compressible, cd.nqv);
-    hipLaunchKernelGGL((k_diag_p<3>), gp, block, 0, s, a, cd.nqv);
+    hipLaunchKernelGGL((k_diag_v<3>), gv, block, 0, s, a, cd.is_compressible, cd.nqv, gen);
+    hipLaunchKernelGGL((k_diag_p<3>), gp, block, 0, s, a, cd.nqv, gen);
   } else {
-    hipLaunchKernelGGL((k_diag_v<2>), gv, block, 0, s, a, cd.is_compressible, cd.nqv);
-    hipLaunchKernelGGL((k_diag_p<2>), gp, block, 0, s, a, cd.nqv);
+    hipLaunchKernelGGL((k_diag_v<2>), gv, block, 0, s, a, cd.is_compressible, cd.nqv, gen);
+    hipLaunchKernelGGL((k_diag_p<2>), gp, block, 0, s, a, cd.nqv, gen);
   }
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
@@ -949,7 +1046,6 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
     if (rc) return rc;
     return launch_pull_v(s, L, slots_u, eu);
   }
-  if (L.geom != AGMG_GEOM_CARTESIAN) { set_error("general (MappingQ) geometry: cell kernels not built yet"); return -3; }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
   const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
@@ -962,16 +1058,12 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
   const bool perq = cd.nqv > 1;
   const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
   const int lds = bt.max_unodes;
+  const bool gen = L.geom == AGMG_GEOM_GENERAL;
   int rc;
-  if (L.dim == 3) {
-    if (which == AGMG_OP_A) rc = launch_blk_t<3, KOP_A>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
-    else if (which == AGMG_OP_STOKES) rc = launch_blk_t<3, KOP_STOKES>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
-    else rc = launch_blk_t<3, KOP_BT>(s, a, b, eu, bt.n_blocks, lds, false, false);
-  } else {
-    if (which == AGMG_OP_A) rc = launch_blk_t<2, KOP_A>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
-    else if (which == AGMG_OP_STOKES) rc = launch_blk_t<2, KOP_STOKES>(s, a, b, eu, bt.n_blocks, lds, comp, perq);
-    else rc = launch_blk_t<2, KOP_BT>(s, a, b, eu, bt.n_blocks, lds, false, false);
-  }
+  if (L.dim == 3) rc = gen ? launch_blk_op<3, true>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq)
+                           : launch_blk_op<3, false>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq);
+  else rc = gen ? launch_blk_op<2, true>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq)
+                : launch_blk_op<2, false>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq);
   if (rc) return rc;
   AGMG_HIP_CHECK(hipGetLastError());
 #if AGMG_ABLATE & 1024

@@ -37,6 +37,10 @@ PROBLEMS = {
     "box3d_r3_freeslip": lambda: cases.convection_box(3, 3),
     "box2d_r3_freeslip": lambda: cases.convection_box(2, 3),
     "solcx_r2": lambda: cases.solcx(2),
+    # general (MappingQ-like) geometry: full q-point Jacobians in every cell kernel
+    "deformed3d_r3_perq": lambda: cases.deformed_sinker_box(3, 3),
+    "deformed3d_r2_harmonic": lambda: cases.deformed_sinker_box(3, 2, averaging=bm.AVG_HARMONIC),
+    "deformed2d_r3_perq": lambda: cases.deformed_sinker_box(2, 3),
 }
 
 
@@ -68,6 +72,32 @@ def test_vmult_nonzero_constrained_entries(pair):
     for which in (capi.OP_A, capi.OP_STOKES):
         src = rand_vec(g.size(which), 5, lev, zero_constrained=False)
         assert relerr(g.vmult(which, src), o.vmult(which, src)) < RTOL
+
+
+def test_vmult_compressible(pair):
+    """is_compressible adds the -2/3 eta div(u) term (matrix_free_operators.cc:243-246, 730-736)."""
+    p, g, o = pair
+    try:
+        for s in (g, o):
+            for l in range(p.hier.n_levels):
+                s._set_coeff(l, p.eta_levels[l], is_compressible=1)
+            s._set_coeff(capi.ACTIVE, p.eta_active, is_compressible=1)
+        for level in (capi.ACTIVE, p.hier.n_levels - 1):
+            lev = p.hier.finest
+            for which in (capi.OP_A, capi.OP_STOKES):
+                src = rand_vec(g.size(which, level), 77 + which, lev)
+                a, b = g.vmult(which, src, level), o.vmult(which, src, level)
+                assert relerr(a, b) < RTOL, (which, level, relerr(a, b))
+        # the term is there: differs from the incompressible operator
+        src = rand_vec(g.size(capi.OP_A), 78, p.hier.finest)
+        comp = g.vmult(capi.OP_A, src)
+    finally:
+        for s in (g, o):
+            for l in range(p.hier.n_levels):
+                s._set_coeff(l, p.eta_levels[l])
+            s._set_coeff(capi.ACTIVE, p.eta_active)
+            s._check(s.lib.compute_diagonals(s.ctx))
+    assert relerr(comp, g.vmult(capi.OP_A, src)) > 1e-3
 
 
 def test_inverse_diagonals(pair):
