@@ -53,6 +53,7 @@ class LevelDesc(C.Structure):
         ("n_neighbors", C.c_int32), ("neighbor_rank", c_i32p),
         ("send_offsets_v", c_i32p), ("send_nodes_v", c_u32p), ("recv_offsets_v", c_i32p),
         ("send_offsets_p", c_i32p), ("send_nodes_p", c_u32p), ("recv_offsets_p", c_i32p),
+        ("global_nodes_v", c_u32p), ("global_nodes_p", c_u32p),
     ]
 
 
@@ -80,7 +81,7 @@ class SolveReport(C.Structure):
 
 # every symbol include/agmg.h declares (suffix after the prefix)
 SYMBOLS = [
-    "default_options", "last_error", "create", "destroy", "set_level", "set_coefficients",
+    "default_options", "last_error", "create", "destroy", "set_communicator", "set_level", "set_coefficients",
     "compute_diagonals", "vmult", "vmult_device", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
     "solve", "bench_vmult", "get_cell_data_memory_consumption",
@@ -124,6 +125,7 @@ class Library:
         self.last_error = fn("last_error", C.c_char_p, [])
         self.create = fn("create", vp, [C.POINTER(Options)])
         self.destroy = fn("destroy", None, [vp])
+        self.set_communicator = fn("set_communicator", C.c_int, [vp, vp])
         self.set_level = fn("set_level", C.c_int, [vp, C.c_int, C.POINTER(LevelDesc)])
         self.set_coefficients = fn("set_coefficients", C.c_int, [vp, C.c_int, C.POINTER(CellData)])
         self.compute_diagonals = fn("compute_diagonals", C.c_int, [vp])
@@ -173,7 +175,7 @@ class Solver:
     equivalent of StokesMatrixFreeHandler's setup_dofs/assemble/
     build_preconditioner/solve sequence)."""
 
-    def __init__(self, lib: Library, problem, single_level=False, **opt_overrides):
+    def __init__(self, lib: Library, problem, single_level=False, transport=None, **opt_overrides):
         self.lib = lib
         self.problem = problem
         hier = problem.hier
@@ -187,6 +189,8 @@ class Solver:
         opt.gmres_restart = problem.restart
         opt.krylov_type = KRYLOV_IDR if problem.krylov == "idr" else KRYLOV_GMRES
         opt.idr_s = problem.idr_s
+        if transport is not None:       # distributed: `problem` is this rank's partition.LocalProblem
+            opt.world_size, opt.rank = transport.struct.size, transport.struct.rank
         for k, v in opt_overrides.items():
             setattr(opt, k, v)
         self.opt = opt
@@ -194,6 +198,9 @@ class Solver:
         if not self.ctx:
             raise AgmgError(lib.last_error().decode())
         self._keep = []
+        self.transport = transport
+        if transport is not None:
+            self._check(lib.set_communicator(self.ctx, C.addressof(transport.struct)))
         for l, lev in enumerate(hier.levels):
             self._set_level(l, lev)
         self._check(lib.set_level(self.ctx, ACTIVE, None))
@@ -235,6 +242,18 @@ class Solver:
         else:
             d.geometry_kind = GEOM_CARTESIAN
             d.cell_h = _ptr(ch, C.c_double)
+        if getattr(lev, "neighbors", None) is not None and self.transport is not None:
+            d.n_owned_nodes_v, d.n_owned_nodes_p = lev.n_owned_nodes_v, lev.n_owned_nodes_p
+            nb = np.ascontiguousarray(lev.neighbors, dtype=np.int32)
+            plan = [np.ascontiguousarray(a) for a in (lev.send_offsets_v, lev.send_nodes_v, lev.recv_offsets_v,
+                                                      lev.send_offsets_p, lev.send_nodes_p, lev.recv_offsets_p,
+                                                      lev.global_nodes_v, lev.global_nodes_p)]
+            d.n_neighbors = nb.size
+            d.neighbor_rank = _ptr(nb, C.c_int32)
+            d.send_offsets_v, d.send_nodes_v, d.recv_offsets_v = _ptr(plan[0], C.c_int32), _ptr(plan[1], C.c_uint32), _ptr(plan[2], C.c_int32)
+            d.send_offsets_p, d.send_nodes_p, d.recv_offsets_p = _ptr(plan[3], C.c_int32), _ptr(plan[4], C.c_uint32), _ptr(plan[5], C.c_int32)
+            d.global_nodes_v, d.global_nodes_p = _ptr(plan[6], C.c_uint32), _ptr(plan[7], C.c_uint32)
+            keep += [nb] + plan
         if l > 0 and lev.level > 0:
             nch = 1 << lev.dim
             par = (np.arange(lev.n_cells, dtype=np.int32) // nch).astype(np.int32)

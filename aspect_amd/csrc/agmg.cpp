@@ -151,6 +151,45 @@ struct agmg_ctx {
   int nA = 0, nS = 0;          // V-cycle / inner iteration counters of the current preconditioner
   std::vector<double> h0, h1;  // host staging for the coarse level
 
+  // ---- distributed contexts: transport callbacks + host staging
+  agmg_comm comm{};
+  bool comm_set = false;
+  double *stage_h = nullptr;   // pinned; device_buffers == 0
+  size_t stage_cap = 0;
+  bool dist() const { return opt.world_size > 1; }
+  struct Msg { int peer; const double *send; int64_t n_send; double *recv; int64_t n_recv; };
+  int exchange(const std::vector<Msg> &msgs);
+  // owner -> ghost copies of `vec` (nc values per node, nc <= x.nc)
+  int add_update(std::vector<Msg> &msgs, const Exchange &x, double *vec, int nc);
+  // ghost partial sums (x.ghostbuf) -> owners (x.expbuf)
+  void add_compress(std::vector<Msg> &msgs, const Exchange &x, int nc);
+  int update_ghosts(const Exchange &x, const double *vec) {
+    if (!x.active()) return 0;
+    std::vector<Msg> m;
+    CHECK(add_update(m, x, const_cast<double *>(vec), x.nc));
+    return exchange(m);
+  }
+  int compress(const Exchange &x) {
+    if (!x.active()) return 0;
+    std::vector<Msg> m;
+    add_compress(m, x, x.nc);
+    return exchange(m);
+  }
+  int allreduce_host(double *v, int n);
+  // A vector of the solve: n local entries (owned + ghost); dot products run over the owned
+  // entries only: logical entry i < n_dot lives at i (i < seg1) or at i + gap
+  struct Span { size_t n, n_dot, seg1, gap; };
+  Span span_of(int which, int l) const {
+    const DeviceLevel &lv = L[l];
+    if (which == 0) { const size_t o = (size_t)lv.n_owned_v * lv.dim; return {(size_t)lv.n_dofs_v(), o, o, 0}; }
+    return {(size_t)lv.n_dofs_p(), (size_t)lv.n_owned_p, (size_t)lv.n_owned_p, 0};
+  }
+  Span span_up() const {
+    const DeviceLevel &lv = L.back();
+    const size_t nu = lv.n_dofs_v(), ou = (size_t)lv.n_owned_v * lv.dim;
+    return {nu + (size_t)lv.n_dofs_p(), ou + (size_t)lv.n_owned_p, ou, nu - ou};
+  }
+
   int nl() const { return (int)L.size(); }
   DeviceLevel &fin() { return L.back(); }
   const CoeffData &active_coeff() { return active.set ? active : fin().coeff; }
@@ -183,17 +222,18 @@ struct agmg_ctx {
 
   bool use_blocks = true;
   void free_level(DeviceLevel &l);
-  int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv);
+  int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
+                         const std::vector<uint32_t> &send_nodes);
   int ensure_workspace();
   int ensure_transfers();
   int ensure_mg_vectors();
   int get_vec(size_t idx, double **p);
 
   // out[k] = <x, ys[k]>, synchronous
-  int dots(const double *x, const std::vector<const double *> &ys, size_t n, double *out);
-  int norm(const double *x, size_t n, double *out) {
+  int dots(const double *x, const std::vector<const double *> &ys, const Span &sp, double *out);
+  int norm(const double *x, const Span &sp, double *out) {
     double v;
-    CHECK(dots(x, {x}, n, &v));
+    CHECK(dots(x, {x}, sp, &v));
     *out = std::sqrt(v);
     return 0;
   }
@@ -217,8 +257,13 @@ struct agmg_ctx {
 
   int precondition(bool expensive, double *dst, const double *src, int *status);
   int solver_cg(const std::function<int(double *, const double *)> &A,
-                const std::function<int(double *, const double *)> &P, double *x, const double *b, size_t n,
+                const std::function<int(double *, const double *)> &P, double *x, const double *b, const Span &sp,
                 int max_it, double tol, double *work[4], int *its, bool *converged);
+  int bt_residual(double *dst, const double *b, const double *p);
+  int restrict_to(int which, int l, const double *src_fine, const EpiArgs &e);
+  int prolongate_from(int which, int l, double *dst_fine, const double *src_coarse);
+  int global_multiplicity(const Exchange &x, const std::vector<uint32_t> &send_nodes_h, std::vector<double> &mult);
+  std::vector<std::vector<uint32_t>> send_nodes_h[2];   // [velocity|pressure][level]: host copy of Exchange::send_nodes
 };
 
 // ===================================================================== memory / setup
@@ -230,13 +275,18 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
   dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8); dfree(l.bt.lidT);
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
+  for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
+  dfree(l.gid_v); dfree(l.gid_p);
   l = DeviceLevel();
 }
 
 // Block-scatter tables (agmg_internal.h BlockTables).  Blocks are runs of consecutive cells in the
 // host's cell order (Morton order keeps them compact); a velocity node is "exclusive" when all
 // cells touching it lie in one block.
-int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv) {
+// Distributed levels: ghost nodes and owned nodes another rank ghosts (`send_nodes`) are always
+// "shared": their sums wait for / feed the ghost exchange in the fix-up kernel.
+int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
+                                 const std::vector<uint32_t> &send_nodes) {
   BlockTables &bt = lv.bt;
   const int dim = lv.dim, NV = ipow(3, dim), nn = lv.n_nodes_v;
   const int cpw = cells_per_wave(dim), bc = cpw * WAVES_PER_BLOCK;
@@ -252,6 +302,8 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
         if (last[node] != b) { last[node] = b; if (nblk[node] < 255) ++nblk[node]; }
       }
   }
+  for (int node = lv.n_owned_v; node < nn; ++node) nblk[node] = std::max<uint8_t>(nblk[node], 2);
+  for (uint32_t node : send_nodes) nblk[node] = std::max<uint8_t>(nblk[node], 2);
   // pass 2: per block unique nodes (exclusive first, each group ascending) and up to 8 LDS
   // slots per node, in (cell, local dof) order.  Tables have a fixed stride max_u per block.
   std::vector<std::vector<uint32_t>> bl_nodes(nb);
@@ -312,11 +364,17 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
     }
     std::vector<uint32_t>().swap(bl_nodes[b]);
   }
-  // fix-up CSR over shared nodes (ascending node order; slots of a node in block order)
-  std::vector<uint32_t> sh_nodes, sh_ptr(1, 0), sh_list(nslots);
+  // remote partial sums: entry k of the receive buffer belongs to owned node send_nodes[k]
+  for (size_t k = 0; k < send_nodes.size(); ++k) {
+    sh_pairs.emplace_back(send_nodes[k], (uint32_t)(nslots + k));
+    ++sh_count[send_nodes[k]];
+  }
+  // fix-up CSR over shared nodes (ascending node order; slots of a node in block order, then remote)
+  std::vector<uint32_t> sh_nodes, sh_ptr(1, 0), sh_list(nslots + send_nodes.size());
   std::vector<uint32_t> sh_index(nn, 0);
   for (int node = 0; node < nn; ++node)
     if (sh_count[node]) {
+      if (node < lv.n_owned_v) bt.n_shared_owned = (int)sh_nodes.size() + 1;
       sh_index[node] = (uint32_t)sh_nodes.size();
       sh_nodes.push_back((uint32_t)node | ((uint32_t)cmv[node] << 29));
       sh_ptr.push_back(sh_ptr.back() + sh_count[node]);
@@ -379,19 +437,122 @@ int agmg_ctx::get_vec(size_t idx, double **p) {
   return 0;
 }
 
-int agmg_ctx::dots(const double *x, const std::vector<const double *> &ys, size_t n, double *out) {
+int agmg_ctx::dots(const double *x, const std::vector<const double *> &ys, const Span &sp, double *out) {
   const int total = (int)ys.size();
   if (total > 256) { set_error("dots: too many vectors"); return -1; }
   for (int k0 = 0; k0 < total; k0 += DOT_MAX_VECS) {
     const int nv = std::min(DOT_MAX_VECS, total - k0);
     VecPtrs vp;
     for (int k = 0; k < DOT_MAX_VECS; ++k) vp.p[k] = ys[k0 + std::min(k, nv - 1)];
-    CHECK(vec_multi_dot(stream, x, vp, nv, n, dot_partials, dot_out_d + k0));
+    CHECK(vec_multi_dot(stream, x, vp, nv, sp.n_dot, sp.seg1, sp.gap, dot_partials, dot_out_d + k0));
+  }
+  if (dist() && comm.device_buffers) {
+    if (comm.allreduce_sum(comm.user, dot_out_d, total, (void *)stream)) { set_error("all-reduce callback failed"); return -101; }
   }
   AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, total * sizeof(double), hipMemcpyDeviceToHost, stream));
   CHECK(sync());
+  if (dist() && !comm.device_buffers) {
+    if (comm.allreduce_sum(comm.user, dot_out_h, total, nullptr)) { set_error("all-reduce callback failed"); return -101; }
+  }
   for (int k = 0; k < total; ++k) out[k] = dot_out_h[k];
   return 0;
+}
+
+// sum over ranks of a few host scalars (setup paths)
+int agmg_ctx::allreduce_host(double *v, int n) {
+  if (!dist()) return 0;
+  if (n > 256) { set_error("allreduce_host: too many values"); return -1; }
+  if (!comm.device_buffers) {
+    if (comm.allreduce_sum(comm.user, v, n, nullptr)) { set_error("all-reduce callback failed"); return -101; }
+    return 0;
+  }
+  CHECK(ensure_workspace());
+  AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_d, v, n * sizeof(double), hipMemcpyHostToDevice, stream));
+  if (comm.allreduce_sum(comm.user, dot_out_d, n, (void *)stream)) { set_error("all-reduce callback failed"); return -101; }
+  AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  CHECK(sync());
+  for (int k = 0; k < n; ++k) v[k] = dot_out_h[k];
+  return 0;
+}
+
+// ===================================================================== ghost exchange
+int agmg_ctx::add_update(std::vector<Msg> &msgs, const Exchange &x, double *vec, int nc) {
+  if (!x.active()) return 0;
+  if (x.n_export > 0) CHECK(vec_gather_nodes(stream, x.expbuf, vec, x.send_nodes, x.n_export, nc));
+  for (size_t k = 0; k < x.nbr.size(); ++k)
+    msgs.push_back({x.nbr[k], x.expbuf + (size_t)x.send_off[k] * nc, (int64_t)(x.send_off[k + 1] - x.send_off[k]) * nc,
+                    vec + ((size_t)x.n_owned + x.recv_off[k]) * nc, (int64_t)(x.recv_off[k + 1] - x.recv_off[k]) * nc});
+  return 0;
+}
+void agmg_ctx::add_compress(std::vector<Msg> &msgs, const Exchange &x, int nc) {
+  for (size_t k = 0; k < x.nbr.size(); ++k)
+    msgs.push_back({x.nbr[k], x.ghostbuf + (size_t)x.recv_off[k] * nc, (int64_t)(x.recv_off[k + 1] - x.recv_off[k]) * nc,
+                    x.expbuf + (size_t)x.send_off[k] * nc, (int64_t)(x.send_off[k + 1] - x.send_off[k]) * nc});
+}
+int agmg_ctx::exchange(const std::vector<Msg> &msgs) {
+  if (msgs.empty()) return 0;
+  if (!comm_set) { set_error("distributed context without a communicator (agmg_set_communicator)"); return -1; }
+  const int n = (int)msgs.size();
+  std::vector<int32_t> peer(n);
+  std::vector<const double *> snd(n);
+  std::vector<double *> rcv(n);
+  std::vector<int64_t> ns(n), nr(n);
+  for (int i = 0; i < n; ++i) { peer[i] = msgs[i].peer; ns[i] = msgs[i].n_send; nr[i] = msgs[i].n_recv; }
+  if (comm.device_buffers) {
+    for (int i = 0; i < n; ++i) { snd[i] = msgs[i].send; rcv[i] = msgs[i].recv; }
+    if (comm.exchange(comm.user, n, peer.data(), snd.data(), ns.data(), rcv.data(), nr.data(), (void *)stream)) {
+      set_error("exchange callback failed"); return -101;
+    }
+    return 0;
+  }
+  size_t tot = 0;
+  for (int i = 0; i < n; ++i) tot += (size_t)(ns[i] + nr[i]);
+  if (tot > stage_cap) {
+    if (stage_h) (void)hipHostFree(stage_h);
+    stage_h = nullptr; stage_cap = 0;
+    AGMG_HIP_CHECK(hipHostMalloc((void **)&stage_h, (tot + tot / 2 + 64) * sizeof(double)));
+    stage_cap = tot + tot / 2 + 64;
+  }
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    snd[i] = stage_h + off;
+    if (ns[i]) AGMG_HIP_CHECK(hipMemcpyAsync(stage_h + off, msgs[i].send, ns[i] * sizeof(double), hipMemcpyDeviceToHost, stream));
+    off += (size_t)ns[i];
+    rcv[i] = stage_h + off;
+    off += (size_t)nr[i];
+  }
+  CHECK(sync());
+  if (comm.exchange(comm.user, n, peer.data(), snd.data(), ns.data(), rcv.data(), nr.data(), nullptr)) {
+    set_error("exchange callback failed"); return -101;
+  }
+  for (int i = 0; i < n; ++i)
+    if (nr[i]) AGMG_HIP_CHECK(hipMemcpyAsync(msgs[i].recv, rcv[i], nr[i] * sizeof(double), hipMemcpyHostToDevice, stream));
+  // the staging buffer is reused by the next exchange: the uploads must have left it
+  return sync();
+}
+
+// number of parent patches containing each fine node, summed over ranks (restriction weights)
+int agmg_ctx::global_multiplicity(const Exchange &x, const std::vector<uint32_t> &snh, std::vector<double> &mult) {
+  if (!x.active()) return 0;
+  const size_t nn = mult.size();
+  double *d;
+  CHECK(dalloc(&d, nn));
+  int rc = h2d(d, mult.data(), nn);
+  std::vector<Msg> m;
+  if (!rc && x.n_ghost) rc = vec_copy(stream, x.ghostbuf, d + x.n_owned, x.n_ghost);
+  if (!rc) { add_compress(m, x, 1); rc = exchange(m); }
+  std::vector<double> got(x.n_export);
+  if (!rc && x.n_export) rc = d2h(got.data(), x.expbuf, x.n_export);
+  if (!rc) {
+    for (int k = 0; k < x.n_export; ++k) mult[snh[k]] += got[k];
+    rc = h2d(d, mult.data(), nn);
+  }
+  m.clear();
+  if (!rc) rc = add_update(m, x, d, 1);
+  if (!rc) rc = exchange(m);
+  if (!rc) rc = d2h(mult.data(), d, nn);
+  dfree(d);
+  return rc;
 }
 
 int agmg_ctx::ensure_transfers() {
@@ -440,10 +601,10 @@ int agmg_ctx::ensure_transfers() {
             if (par[fn] == 0xFFFFFFFFu) { par[fn] = p; pos[fn] = (uint8_t)pidx; }
           }
         }
-      for (int i = 0; i < nn; ++i) {
+      for (int i = 0; i < nn; ++i)
         if (par[i] == 0xFFFFFFFFu) { par[i] = 0; mult[i] = 1.0; }  // node not touched by any cell
-        mult[i] = 1.0 / mult[i];
-      }
+      if (dist()) CHECK(global_multiplicity(vel ? F.xv : F.xp, send_nodes_h[vel ? 0 : 1][l], mult));
+      for (int i = 0; i < nn; ++i) mult[i] = 1.0 / mult[i];
       if (vel) { CHECK(upload(&F.prol_parent_v, par)); CHECK(upload(&F.prol_pos_v, pos)); CHECK(upload(&F.inv_mult_v, mult)); }
       else { CHECK(upload(&F.prol_parent_p, par)); CHECK(upload(&F.prol_pos_p, pos)); CHECK(upload(&F.inv_mult_p, mult)); }
       F.bytes_transfer += (size_t)nn * (4 + 1 + 8);
@@ -456,9 +617,54 @@ int agmg_ctx::ensure_transfers() {
 // ===================================================================== operators
 int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e) {
   const DeviceLevel &lv = L[l];
-  if (which == 0) return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks);
+  if (!dist()) {
+    if (which == 0) return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks);
+    CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
+    return launch_pull_p(stream, lv, slots_p, 1, e);
+  }
+  // distributed: src.update_ghost_values(); cell loop; dst.compress(add); epilogue on the owned rows
+  if (which == 0) {
+    CHECK(update_ghosts(lv.xv, x));
+    CHECK(launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_GHOST));
+    CHECK(compress(lv.xv));
+    return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_OWNED);
+  }
+  CHECK(update_ghosts(lv.xp, x));
   CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
-  return launch_pull_p(stream, lv, slots_p, 1, e);
+  CHECK(launch_pull_p(stream, lv, slots_p, 1, e, PH_GHOST));
+  CHECK(compress(lv.xp));
+  return launch_pull_p(stream, lv, slots_p, 1, e, PH_OWNED);
+}
+
+// dst = b - B^T p on the active mesh (velocity rows; stokes_matrix_free.h:299-303)
+int agmg_ctx::bt_residual(double *dst, const double *b, const double *p) {
+  const DeviceLevel &lv = fin();
+  EpiArgs e;
+  e.epi = b ? EPI_RESID : EPI_STORE; e.dst = dst; e.b = b; e.x = nullptr;
+  if (!dist()) return launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks);
+  CHECK(update_ghosts(lv.xp, p));
+  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_GHOST));
+  CHECK(compress(lv.xv));
+  return launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_OWNED);
+}
+
+// defect[l-1] (epilogue e on level l-1) from R * src_fine, src_fine on level l
+int agmg_ctx::restrict_to(int which, int l, const double *src_fine, const EpiArgs &e) {
+  const DeviceLevel &F = L[l], &C = L[l - 1];
+  const bool vel = which == 0;
+  double *slots = vel ? slots_u : slots_p;
+  if (dist()) CHECK(update_ghosts(vel ? F.xv : F.xp, src_fine));
+  CHECK(launch_restrict_cells(stream, F, C, vel, src_fine, slots));
+  if (!dist()) return vel ? launch_pull_v(stream, C, slots, e) : launch_pull_p(stream, C, slots, 1, e);
+  CHECK(vel ? launch_pull_v(stream, C, slots, e, PH_GHOST) : launch_pull_p(stream, C, slots, 1, e, PH_GHOST));
+  CHECK(compress(vel ? C.xv : C.xp));
+  return vel ? launch_pull_v(stream, C, slots, e, PH_OWNED) : launch_pull_p(stream, C, slots, 1, e, PH_OWNED);
+}
+int agmg_ctx::prolongate_from(int which, int l, double *dst_fine, const double *src_coarse) {
+  const DeviceLevel &F = L[l], &C = L[l - 1];
+  const bool vel = which == 0;
+  if (dist()) CHECK(update_ghosts(vel ? C.xv : C.xp, src_coarse));
+  return launch_prolongate_add(stream, F, C, vel, dst_fine, src_coarse);
 }
 
 // Stokes operator on the active mesh; epilogue kind/b taken from eu_in (STORE or RESID)
@@ -469,8 +675,22 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
   eu.dst = dst; eu.x = src;
   ep.dst = dst + nu; ep.x = src + nu;
   if (eu_in.b) ep.b = eu_in.b + nu;
-  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks));
-  return launch_pull_p(stream, lv, slots_p, lv.dim, ep);
+  if (!dist()) {
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks));
+    return launch_pull_p(stream, lv, slots_p, lv.dim, ep);
+  }
+  std::vector<Msg> m;
+  CHECK(add_update(m, lv.xv, const_cast<double *>(src), lv.xv.nc));
+  CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
+  CHECK(exchange(m));
+  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_GHOST));
+  CHECK(launch_pull_p(stream, lv, slots_p, lv.dim, ep, PH_GHOST));
+  m.clear();
+  add_compress(m, lv.xv, lv.xv.nc);
+  add_compress(m, lv.xp, 1);
+  CHECK(exchange(m));
+  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_OWNED));
+  return launch_pull_p(stream, lv, slots_p, lv.dim, ep, PH_OWNED);
 }
 int agmg_ctx::stokes_vmult(double *dst, const double *src) {
   EpiArgs e;
@@ -544,7 +764,7 @@ int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
 
 // level 0: MGCoarseGridApplySmoother = smoother apply (local_smoothing.cc:999-1004)
 int agmg_ctx::coarse_solve(int which) {
-  if (!opt.coarse_on_host) return smoother_apply(which, 0, mg_def[which][0]);
+  if (!opt.coarse_on_host || dist()) return smoother_apply(which, 0, mg_def[which][0]);
   const CoarseOp &co = coarse[which];
   const Smoother &s = sm[which][0];
   const int n = co.n, steps = which == 0 ? 1 : opt.schur_smoother_steps;
@@ -593,8 +813,7 @@ int agmg_ctx::coarse_solve(int which) {
 // Multigrid::level_v_step; uniformly refined meshes: no edge matrices
 int agmg_ctx::level_v_step(int which, int l) {
   if (l == 0) return coarse_solve(which);
-  const DeviceLevel &F = L[l], &C = L[l - 1];
-  const bool vel = which == 0;
+  const DeviceLevel &F = L[l];
   CHECK(smoother_apply(which, l, mg_def[which][l]));
   {  // t = defect - A solution
     EpiArgs e;
@@ -602,15 +821,12 @@ int agmg_ctx::level_v_step(int which, int l) {
     CHECK(apply_level(which, l, F.coeff, mg_sol[which][l], e));
   }
   {  // defect[l-1] = R t   (coarse Dirichlet rows dropped)
-    double *slots = vel ? slots_u : slots_p;
-    CHECK(launch_restrict_cells(stream, F, C, vel, mg_t[which][l], slots));
     EpiArgs e;
     e.epi = EPI_STORE; e.dst = mg_def[which][l - 1]; e.x = nullptr;
-    if (vel) CHECK(launch_pull_v(stream, C, slots, e));
-    else CHECK(launch_pull_p(stream, C, slots, 1, e));
+    CHECK(restrict_to(which, l, mg_t[which][l], e));
   }
   CHECK(level_v_step(which, l - 1));
-  CHECK(launch_prolongate_add(stream, F, C, vel, mg_sol[which][l], mg_sol[which][l - 1]));
+  CHECK(prolongate_from(which, l, mg_sol[which][l], mg_sol[which][l - 1]));
   return smoother_smooth(which, l, mg_def[which][l]);
 }
 
@@ -627,7 +843,8 @@ int agmg_ctx::vcycle(int which, double *dst, const double *src) {
 
 // eigenvalue estimate by eig_cg_n_iterations steps of Jacobi-preconditioned CG on the device
 int agmg_ctx::estimate_device(int which, int l) {
-  const size_t n = size_of(which, l);
+  const Span sp = span_of(which, l);
+  const size_t n = sp.n;
   const bool coarse_lvl = l == 0;
   Smoother &s = sm[which][l];
   s.degree = coarse_lvl ? opt.coarse_degree : opt.smoother_degree;
@@ -636,23 +853,28 @@ int agmg_ctx::estimate_device(int which, int l) {
   const double *dinv = which == 0 ? L[l].inv_diag_A : L[l].inv_diag_M;
   double *g = mg_def[which][l], *h = mg_sol[which][l], *d = mg_tmp[which][l], *Ad = mg_t[which][l];
   // start vector: (index mod 11) minus its mean
-  CHECK(vec_fill_index_mod(stream, g, n, 11));
+  // (by GLOBAL index in a distributed context, so the estimate does not depend on the partition)
+  const uint32_t *gid = which == 0 ? L[l].gid_v : L[l].gid_p;
+  if (gid) CHECK(vec_fill_gid_mod(stream, g, gid, which == 0 ? L[l].n_nodes_v : L[l].n_nodes_p, which == 0 ? L[l].dim : 1, 11));
+  else CHECK(vec_fill_index_mod(stream, g, n, 11));
+  double n_glob = (double)sp.n_dot;
+  CHECK(allreduce_host(&n_glob, 1));
   double sum = 0;
   {
-    const size_t full = n / 11, rem = n % 11;
+    const size_t ng = (size_t)n_glob, full = ng / 11, rem = ng % 11;
     sum = (double)full * 55.0 + (double)(rem * (rem - 1) / 2);
   }
-  CHECK(vec_shift(stream, g, -sum / (double)n, n));
+  CHECK(vec_shift(stream, g, -sum / n_glob, n));
   Lanczos lz;
   double res;
-  CHECK(norm(g, n, &res));
+  CHECK(norm(g, sp, &res));
   const double tol = 1e-10;
   if (res > tol && max_it > 0) {
     double gh = 0, alpha = 0, beta = 0;
     for (int it = 1;; ++it) {
       CHECK(vec_pointwise_scale(stream, h, 1.0, dinv, g, n));
       const double gh_old = gh;
-      CHECK(dots(g, {h}, n, &gh));
+      CHECK(dots(g, {h}, sp, &gh));
       if (it > 1) {
         beta = gh / gh_old;
         CHECK(vec_sadd(stream, d, beta, 1.0, h, n));
@@ -661,10 +883,10 @@ int agmg_ctx::estimate_device(int which, int l) {
       e.epi = EPI_STORE; e.dst = Ad; e.x = d;
       CHECK(apply_level(which, l, L[l].coeff, d, e));
       double dAd;
-      CHECK(dots(d, {Ad}, n, &dAd));
+      CHECK(dots(d, {Ad}, sp, &dAd));
       alpha = gh / dAd;
       CHECK(vec_axpy(stream, g, -alpha, Ad, n));
-      CHECK(norm(g, n, &res));
+      CHECK(norm(g, sp, &res));
       lz.push(it, alpha, beta);
       if (res <= tol || it >= max_it || !std::isfinite(res)) break;
     }
@@ -744,7 +966,7 @@ int agmg_ctx::setup_smoothers() {
   CHECK(ensure_mg_vectors());
   for (int w = 0; w < 2; ++w)
     for (int l = 0; l < nl(); ++l) {
-      if (l == 0 && opt.coarse_on_host) CHECK(build_coarse(w));
+      if (l == 0 && opt.coarse_on_host && !dist()) CHECK(build_coarse(w));
       else CHECK(estimate_device(w, l));
     }
   smoothers_ready = true;
@@ -754,13 +976,14 @@ int agmg_ctx::setup_smoothers() {
 // ===================================================================== block preconditioner
 // deal.II SolverCG on device vectors; work = {g, d, h, Ad}
 int agmg_ctx::solver_cg(const std::function<int(double *, const double *)> &A,
-                        const std::function<int(double *, const double *)> &P, double *x, const double *b, size_t n,
+                        const std::function<int(double *, const double *)> &P, double *x, const double *b, const Span &sp,
                         int max_it, double tol, double *work[4], int *its, bool *converged) {
+  const size_t n = sp.n;
   double *g = work[0], *d = work[1], *h = work[2], *Ad = work[3];
   CHECK(A(g, x));
   CHECK(vec_lincomb(stream, g, 1.0, b, -1.0, g, n));
   double res;
-  CHECK(norm(g, n, &res));
+  CHECK(norm(g, sp, &res));
   *its = 0;
   *converged = false;
   if (res <= tol) { *converged = true; return 0; }
@@ -768,18 +991,18 @@ int agmg_ctx::solver_cg(const std::function<int(double *, const double *)> &A,
   for (int it = 1;; ++it) {
     CHECK(P(h, g));
     const double gh_old = gh;
-    CHECK(dots(g, {h}, n, &gh));
+    CHECK(dots(g, {h}, sp, &gh));
     if (it > 1) {
       beta = gh / gh_old;
       CHECK(vec_sadd(stream, d, beta, 1.0, h, n));
     } else CHECK(vec_copy(stream, d, h, n));
     CHECK(A(Ad, d));
     double dAd;
-    CHECK(dots(d, {Ad}, n, &dAd));
+    CHECK(dots(d, {Ad}, sp, &dAd));
     alpha = gh / dAd;
     CHECK(vec_axpy(stream, x, alpha, d, n));
     CHECK(vec_axpy(stream, g, -alpha, Ad, n));
-    CHECK(norm(g, n, &res));
+    CHECK(norm(g, sp, &res));
     *its = it;
     if (res <= tol) { *converged = true; break; }
     if (it >= max_it || !std::isfinite(res)) break;
@@ -798,7 +1021,7 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
   CHECK(get_vec(0, &utmp));
   if (expensive) {
     double nrm;
-    CHECK(norm(src_p, np, &nrm));
+    CHECK(norm(src_p, span_of(1, top), &nrm));
     CHECK(vec_set(stream, dst_p, 0.0, np));
     if (nrm > 1e-50) {
       double *w0, *w1;
@@ -810,7 +1033,7 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
       };
       auto Pop = [&](double *d, const double *s) { return vcycle(1, d, s); };
       int its; bool conv;
-      CHECK(solver_cg(Aop, Pop, dst_p, src_p, np, 100, nrm * opt.S_block_tolerance, work, &its, &conv));
+      CHECK(solver_cg(Aop, Pop, dst_p, src_p, span_of(1, top), 100, nrm * opt.S_block_tolerance, work, &its, &conv));
       nS += its;
       if (!conv && status) *status = -2;
     }
@@ -819,14 +1042,10 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
     nS += 1;
   }
   CHECK(vec_scale(stream, dst_p, -1.0, np));
-  {  // utmp = src_u - B^T dst_p
-    EpiArgs e;
-    e.epi = EPI_RESID; e.dst = utmp; e.b = src_u; e.x = nullptr;
-    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, dst_p, slots_u, nullptr, e, use_blocks));
-  }
+  CHECK(bt_residual(utmp, src_u, dst_p));  // utmp = src_u - B^T dst_p
   if (expensive) {
     double nrm;
-    CHECK(norm(utmp, nu, &nrm));
+    CHECK(norm(utmp, span_of(0, top), &nrm));
     CHECK(vec_set(stream, dst_u, 0.0, nu));
     double *w[4];
     for (int i = 0; i < 4; ++i) CHECK(get_vec(1 + i, &w[i]));
@@ -836,7 +1055,7 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
     };
     auto Pop = [&](double *d, const double *s) { return vcycle(0, d, s); };
     int its; bool conv;
-    CHECK(solver_cg(Aop, Pop, dst_u, utmp, nu, 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
+    CHECK(solver_cg(Aop, Pop, dst_u, utmp, span_of(0, top), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
     nA += its;
     if (!conv && status) *status = -3;
   } else {
@@ -897,24 +1116,26 @@ int multi_axpy(agmg_ctx *c, double *y, const std::vector<const double *> &xs, co
 
 // orthogonalise w against V[0..j] (classical Gram-Schmidt, fused dots, one re-orthogonalisation);
 // h[0..j] receives the coefficients, h[j+1] the norm of the remainder
-int orthogonalize(agmg_ctx *c, double *w, const std::vector<double *> &V, int j, size_t n, std::vector<double> &h) {
+int orthogonalize(agmg_ctx *c, double *w, const std::vector<double *> &V, int j, const agmg_ctx::Span &sp, std::vector<double> &h) {
+  const size_t n = sp.n;
   std::vector<const double *> vs(V.begin(), V.begin() + j + 1);
   std::vector<double> hh(j + 1), neg(j + 1);
   h.assign(j + 2, 0.0);
   for (int pass = 0; pass < 2; ++pass) {
-    CHECK(c->dots(w, vs, n, hh.data()));
+    CHECK(c->dots(w, vs, sp, hh.data()));
     for (int i = 0; i <= j; ++i) { h[i] += hh[i]; neg[i] = -hh[i]; }
     CHECK(multi_axpy(c, w, vs, neg, n));
   }
   double s;
-  CHECK(c->norm(w, n, &s));
+  CHECK(c->norm(w, sp, &s));
   h[j + 1] = s;
   return 0;
 }
 
 // deal.II SolverGMRES, right preconditioning: x += P^-1 (V y) at convergence / restart
-int solver_gmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, size_t n, int restart,
+int solver_gmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, const agmg_ctx::Span &sp, int restart,
                  Control &ctl, size_t pool0, int *state_out) {
+  const size_t n = sp.n;
   std::vector<double *> V;
   double *p, *w;
   CHECK(c->get_vec(pool0, &p));
@@ -927,7 +1148,7 @@ int solver_gmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double 
     CHECK(basis(0, &v0));
     CHECK(c->stokes_residual(v0, b, x));
     double rho;
-    CHECK(c->norm(v0, n, &rho));
+    CHECK(c->norm(v0, sp, &rho));
     state = ctl.check(acc, rho);
     if (state != ST_ITERATE) break;
     CHECK(vec_scale(c->stream, v0, 1.0 / rho, n));
@@ -940,7 +1161,7 @@ int solver_gmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double 
       CHECK(P(p, V[j]));
       CHECK(A(w, p));
       std::vector<double> h;
-      CHECK(orthogonalize(c, w, V, j, n, h));
+      CHECK(orthogonalize(c, w, V, j, sp, h));
       double *vn;
       CHECK(basis(j + 1, &vn));
       const double s = h[j + 1];
@@ -961,8 +1182,9 @@ int solver_gmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double 
 }
 
 // deal.II SolverFGMRES(max_basis_size)
-int solver_fgmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, size_t n, int basis_size,
+int solver_fgmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, const agmg_ctx::Span &sp, int basis_size,
                   Control &ctl, size_t pool0, int *state_out) {
+  const size_t n = sp.n;
   double *aux;
   CHECK(c->get_vec(pool0, &aux));
   auto vvec = [&](int i, double **v) { return c->get_vec(pool0 + 1 + 2 * i, v); };
@@ -971,7 +1193,7 @@ int solver_fgmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double
   do {
     CHECK(c->stokes_residual(aux, b, x));
     double beta;
-    CHECK(c->norm(aux, n, &beta));
+    CHECK(c->norm(aux, sp, &beta));
     state = ctl.check(acc, beta);
     if (state != ST_ITERATE) break;
     std::vector<double *> V, Z;
@@ -989,7 +1211,7 @@ int solver_fgmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double
       Z.push_back(z);
       CHECK(A(aux, z));
       std::vector<double> h;
-      CHECK(orthogonalize(c, aux, V, j, n, h));
+      CHECK(orthogonalize(c, aux, V, j, sp, h));
       CHECK(vvec(j + 1, &v));
       const double a = h[j + 1];
       CHECK(vec_lincomb(c->stream, v, a != 0 ? 1.0 / a : 0.0, aux, 0.0, aux, n));
@@ -1005,8 +1227,9 @@ int solver_fgmres(agmg_ctx *c, const Op &A, const Op &P, double *x, const double
 }
 
 // deal.II SolverIDR(s), right preconditioned (van Gijzen & Sonneveld, bi-orthogonal variant)
-int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, size_t n, int s, Control &ctl,
+int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b, const agmg_ctx::Span &sp, int s, Control &ctl,
                size_t pool0, int *state_out) {
+  const size_t n = sp.n;
   double *r, *v, *vhat, *uhat, *ghat;
   size_t k0 = pool0;
   CHECK(c->get_vec(k0++, &r)); CHECK(c->get_vec(k0++, &v)); CHECK(c->get_vec(k0++, &vhat));
@@ -1016,7 +1239,7 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
   hipStream_t st = c->stream;
   CHECK(c->stokes_residual(r, b, x));
   double res;
-  CHECK(c->norm(r, n, &res));
+  CHECK(c->norm(r, sp, &res));
   int step = 0;
   int state = ctl.check(step, res);
   *state_out = state;
@@ -1034,12 +1257,12 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
     } else CHECK(vec_copy(st, Q[i], r, n));
     for (int j = 0; j < i; ++j) {
       double d2[2];
-      CHECK(c->dots(Q[j], {Q[i], Q[j]}, n, d2));
+      CHECK(c->dots(Q[j], {Q[i], Q[j]}, sp, d2));
       CHECK(vec_axpy(st, Q[i], -d2[0] / d2[1], Q[j], n));
     }
     if (i != 0) {
       double nn;
-      CHECK(c->norm(Q[i], n, &nn));
+      CHECK(c->norm(Q[i], sp, &nn));
       CHECK(vec_scale(st, Q[i], 1.0 / nn, n));
     }
     M[i][i] = 1.0;
@@ -1049,7 +1272,7 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
   while (state == ST_ITERATE) {
     ++step;
     std::vector<double> phi(s);
-    CHECK(c->dots(r, std::vector<const double *>(Q.begin(), Q.end()), n, phi.data()));
+    CHECK(c->dots(r, std::vector<const double *>(Q.begin(), Q.end()), sp, phi.data()));
     for (int k = 0; k < s; ++k) {
       std::vector<double> gamma(s - k);
       for (int i = k; i < s; ++i) {
@@ -1065,12 +1288,12 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
       CHECK(A(ghat, uhat));
       if (k > 0) {
         double dq;
-        CHECK(c->dots(Q[0], {ghat}, n, &dq));
+        CHECK(c->dots(Q[0], {ghat}, sp, &dq));
         double alpha = dq / M[0][0];
         for (int i = 1; i < k; ++i) {
           CHECK(vec_axpy(st, ghat, -alpha, G[i - 1], n));
           CHECK(vec_axpy(st, uhat, -alpha, U[i - 1], n));
-          CHECK(c->dots(Q[i], {ghat}, n, &dq));
+          CHECK(c->dots(Q[i], {ghat}, sp, &dq));
           alpha = dq / M[i][i];
         }
         CHECK(vec_axpy(st, ghat, -alpha, G[k - 1], n));
@@ -1080,13 +1303,13 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
       std::swap(U[k], uhat);
       {
         std::vector<double> col(s - k);
-        CHECK(c->dots(G[k], std::vector<const double *>(Q.begin() + k, Q.end()), n, col.data()));
+        CHECK(c->dots(G[k], std::vector<const double *>(Q.begin() + k, Q.end()), sp, col.data()));
         for (int i = k; i < s; ++i) M[i][k] = col[i - k];
       }
       const double beta = phi[k] / M[k][k];
       CHECK(vec_axpy(st, r, -beta, G[k], n));
       CHECK(vec_axpy(st, x, beta, U[k], n));
-      CHECK(c->norm(r, n, &res));
+      CHECK(c->norm(r, sp, &res));
       state = ctl.check(step, res);
       if (state != ST_ITERATE) { early = true; break; }
       if (k + 1 < s) {
@@ -1098,11 +1321,11 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
     CHECK(P(vhat, r));
     CHECK(A(v, vhat));
     double d2[2];
-    CHECK(c->dots(v, {r, v}, n, d2));
+    CHECK(c->dots(v, {r, v}, sp, d2));
     omega = d2[0] / d2[1];
     CHECK(vec_axpy(st, r, -omega, v, n));
     CHECK(vec_axpy(st, x, omega, vhat, n));
-    CHECK(c->norm(r, n, &res));
+    CHECK(c->norm(r, sp, &res));
     state = ctl.check(step, res);
   }
   *state_out = state;
@@ -1134,7 +1357,10 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (opt->dim != 2 && opt->dim != 3) { set_error("dim must be 2 or 3"); return nullptr; }
   if (opt->degree_v != 2) { set_error("only Stokes velocity polynomial degree 2 (Q2-Q1) is built"); return nullptr; }
   if (opt->n_levels < 1) { set_error("n_levels must be >= 1"); return nullptr; }
-  if (opt->world_size != 1) { set_error("world_size > 1: ghost exchange is not built yet (DESIGN.md, multi-GPU)"); return nullptr; }
+  if (opt->world_size < 1 || opt->rank < 0 || opt->rank >= opt->world_size) { set_error("bad world_size / rank"); return nullptr; }
+  if (opt->world_size > 1 && opt->krylov_type == AGMG_KRYLOV_IDR) {
+    set_error("IDR(s) in a distributed context is not built (its random shadow space is generated per rank)"); return nullptr;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: this library has no CPU path"); return nullptr; }
   if (opt->device < 0 || opt->device >= ndev) { set_error("bad device ordinal"); return nullptr; }
@@ -1144,8 +1370,18 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
   c->L.resize(opt->n_levels);
   c->H.resize(opt->n_levels);
+  for (int w = 0; w < 2; ++w) c->send_nodes_h[w].resize(opt->n_levels);
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
   return c;
+}
+
+int agmg_set_communicator(agmg_ctx *c, const agmg_comm *comm) {
+  if (!c || !comm) { set_error("null argument"); return -1; }
+  if (!comm->exchange || !comm->allreduce_sum) { set_error("communicator without callbacks"); return -1; }
+  if (comm->size != c->opt.world_size || comm->rank != c->opt.rank) { set_error("communicator rank/size differ from the context's options"); return -1; }
+  c->comm = *comm;
+  c->comm_set = true;
+  return 0;
 }
 
 void agmg_destroy(agmg_ctx *c) {
@@ -1161,6 +1397,7 @@ void agmg_destroy(agmg_ctx *c) {
   for (auto &p : c->pool) c->dfree(p);
   c->dfree(c->dot_partials); c->dfree(c->dot_out_d);
   if (c->dot_out_h) (void)hipHostFree(c->dot_out_h);
+  if (c->stage_h) (void)hipHostFree(c->stage_h);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1176,7 +1413,26 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   if (!d || d->n_cells <= 0 || !d->cell_nodes_v || !d->cell_nodes_p || !d->constrained_v) { set_error("incomplete level descriptor"); return -1; }
   const int dim = c->opt.dim, NV = ipow(3, dim), NP = ipow(2, dim);
   if ((unsigned)d->n_nodes_v > NODE_MASK || (unsigned)d->n_nodes_p > NODE_MASK) { set_error("too many nodes for 29-bit indices"); return -1; }
-  if (d->n_owned_nodes_v != d->n_nodes_v || d->n_owned_nodes_p != d->n_nodes_p || d->n_neighbors != 0) {
+  const bool has_plan = d->n_owned_nodes_v != d->n_nodes_v || d->n_owned_nodes_p != d->n_nodes_p || d->n_neighbors != 0;
+  if (has_plan && c->dist()) {
+    if (!c->comm_set) { set_error("set_level: bind the transport first (agmg_set_communicator)"); return -1; }
+    if (d->n_neighbors < 0 || (d->n_neighbors > 0 && (!d->neighbor_rank || !d->send_offsets_v || !d->recv_offsets_v ||
+                                                      !d->send_offsets_p || !d->recv_offsets_p))) {
+      set_error("incomplete ghost exchange plan"); return -1;
+    }
+    if (d->n_owned_nodes_v < 0 || d->n_owned_nodes_v > d->n_nodes_v || d->n_owned_nodes_p < 0 || d->n_owned_nodes_p > d->n_nodes_p) {
+      set_error("bad owned node counts"); return -1;
+    }
+    for (int k = 0; k < d->n_neighbors; ++k)
+      if (d->neighbor_rank[k] < 0 || d->neighbor_rank[k] >= c->opt.world_size || d->neighbor_rank[k] == c->opt.rank) {
+        set_error("bad neighbour rank"); return -1;
+      }
+    if (d->n_neighbors > 0 &&
+        (d->recv_offsets_v[d->n_neighbors] != d->n_nodes_v - d->n_owned_nodes_v ||
+         d->recv_offsets_p[d->n_neighbors] != d->n_nodes_p - d->n_owned_nodes_p)) {
+      set_error("ghost groups do not cover the ghost nodes"); return -1;
+    }
+  } else if (has_plan) {
     set_error("ghost nodes / neighbours given but world_size == 1");
     return -1;
   }
@@ -1195,12 +1451,47 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   const uint8_t vmask = (uint8_t)((1u << dim) - 1u);
   for (auto &m : cmv) m &= vmask;
   for (auto &m : cmp) m &= 1u;
+  lv.n_owned_v = lv.n_nodes_v; lv.n_owned_p = lv.n_nodes_p;
+  for (int w = 0; w < 2; ++w) c->send_nodes_h[w][level].clear();
+  if (has_plan) {  // ghost exchange plans of the two node spaces
+    lv.n_owned_v = d->n_owned_nodes_v; lv.n_owned_p = d->n_owned_nodes_p;
+    for (int vel = 0; vel < 2; ++vel) {
+      Exchange &x = vel ? lv.xv : lv.xp;
+      const int32_t *so = vel ? d->send_offsets_v : d->send_offsets_p, *ro = vel ? d->recv_offsets_v : d->recv_offsets_p;
+      const uint32_t *sn = vel ? d->send_nodes_v : d->send_nodes_p;
+      x.nc = vel ? dim : 1;
+      x.n_owned = vel ? lv.n_owned_v : lv.n_owned_p;
+      x.n_ghost = (vel ? lv.n_nodes_v : lv.n_nodes_p) - x.n_owned;
+      x.nbr.assign(d->neighbor_rank, d->neighbor_rank + d->n_neighbors);
+      x.send_off.assign(so, so + d->n_neighbors + 1);
+      x.recv_off.assign(ro, ro + d->n_neighbors + 1);
+      x.n_export = d->n_neighbors ? so[d->n_neighbors] : 0;
+      for (int k = 0; k < d->n_neighbors; ++k)
+        if (so[k + 1] < so[k] || ro[k + 1] < ro[k] || so[0] != 0 || ro[0] != 0) { set_error("exchange offsets must be non-decreasing from 0"); return -1; }
+      if (x.n_export > 0 && !sn) { set_error("send_nodes missing"); return -1; }
+      std::vector<uint32_t> &snh = c->send_nodes_h[vel ? 0 : 1][level];
+      snh.assign(sn, sn + x.n_export);
+      for (uint32_t node : snh) if ((int)node >= x.n_owned) { set_error("send_nodes must be owned nodes"); return -1; }
+      CHECK(c->upload(&x.send_nodes, snh));
+      CHECK(c->dalloc(&x.expbuf, (size_t)x.n_export * x.nc));
+      CHECK(c->dalloc(&x.ghostbuf, (size_t)x.n_ghost * x.nc));
+      lv.bytes_tables += snh.size() * 4;
+    }
+  }
+  for (int vel = 0; vel < 2; ++vel) {
+    const uint32_t *gn = vel ? d->global_nodes_v : d->global_nodes_p;
+    if (gn && c->dist()) {
+      std::vector<uint32_t> g(gn, gn + (vel ? lv.n_nodes_v : lv.n_nodes_p));
+      CHECK(c->upload(vel ? &lv.gid_v : &lv.gid_p, g));
+    }
+  }
   for (int vel = 0; vel < 2; ++vel) {
     const int nloc = vel ? NV : NP, nn = vel ? lv.n_nodes_v : lv.n_nodes_p;
     const std::vector<uint32_t> &cn = vel ? hl.cnv : hl.cnp;
     const std::vector<uint8_t> &cm = vel ? cmv : cmp;
+    const std::vector<uint32_t> &snh = c->send_nodes_h[vel ? 0 : 1][level];
     std::vector<uint32_t> T((size_t)nloc * cs);
-    std::vector<uint32_t> ptr((size_t)nn + 1, 0), list((size_t)lv.n_cells * nloc);
+    std::vector<uint32_t> ptr((size_t)nn + 1, 0), list((size_t)lv.n_cells * nloc + snh.size());
     for (int cell = 0; cell < lv.n_cells; ++cell)
       for (int a = 0; a < nloc; ++a) {
         const uint32_t node = cn[(size_t)cell * nloc + a];
@@ -1210,6 +1501,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
       }
     for (size_t cell = lv.n_cells; cell < cs; ++cell)
       for (int a = 0; a < nloc; ++a) T[(size_t)a * cs + cell] = T[(size_t)a * cs + lv.n_cells - 1];
+    for (uint32_t node : snh) ++ptr[node + 1];   // remote partial sums (receive buffer entries)
     for (int i = 0; i < nn; ++i) ptr[i + 1] += ptr[i];
     std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
     for (int cell = 0; cell < lv.n_cells; ++cell)
@@ -1217,6 +1509,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
         const uint32_t node = cn[(size_t)cell * nloc + a];
         list[fill[node]++] = (uint32_t)((size_t)a * cs + cell);
       }
+    for (size_t k = 0; k < snh.size(); ++k) list[fill[snh[k]]++] = (uint32_t)((size_t)nloc * cs + k);
     if (vel) { CHECK(c->upload(&lv.cnvT, T)); CHECK(c->upload(&lv.pull_ptr_v, ptr)); CHECK(c->upload(&lv.pull_list_v, list)); CHECK(c->upload(&lv.cmask_v, cmv)); }
     else { CHECK(c->upload(&lv.cnpT, T)); CHECK(c->upload(&lv.pull_ptr_p, ptr)); CHECK(c->upload(&lv.pull_list_p, list)); CHECK(c->upload(&lv.cmask_p, cmp)); }
     lv.bytes_tables += (T.size() + ptr.size() + list.size()) * 4;
@@ -1253,7 +1546,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     hl.parent.assign(d->parent_cell, d->parent_cell + lv.n_cells);
     hl.child.assign(d->child_index, d->child_index + lv.n_cells);
   }
-  CHECK(c->build_block_tables(lv, hl, cmv));
+  CHECK(c->build_block_tables(lv, hl, cmv, c->send_nodes_h[0][level]));
   lv.bytes_tables += lv.bt.bytes;
   CHECK(c->dalloc(&lv.inv_diag_A, (size_t)lv.n_dofs_v()));
   CHECK(c->dalloc(&lv.inv_diag_M, (size_t)lv.n_dofs_p()));
@@ -1305,12 +1598,23 @@ int agmg_compute_diagonals(agmg_ctx *c) {
   CHECK(c->ensure_workspace());
   for (auto &l : c->L) {
     CHECK(launch_diag_cells(c->stream, l, l.coeff, c->slots_u, c->slots_p));
-    EpiArgs e;
-    e.epi = EPI_DIAG;
-    e.dst = l.inv_diag_A;
-    CHECK(launch_pull_v(c->stream, l, c->slots_u, e));
-    e.dst = l.inv_diag_M;
-    CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, e));
+    EpiArgs eA, eM;
+    eA.epi = eM.epi = EPI_DIAG;
+    eA.dst = l.inv_diag_A;
+    eM.dst = l.inv_diag_M;
+    if (!c->dist()) {
+      CHECK(launch_pull_v(c->stream, l, c->slots_u, eA));
+      CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, eM));
+    } else {  // cell diagonals of interface nodes are summed over the ranks sharing them
+      CHECK(launch_pull_v(c->stream, l, c->slots_u, eA, PH_GHOST));
+      CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, eM, PH_GHOST));
+      std::vector<agmg_ctx::Msg> m;
+      c->add_compress(m, l.xv, l.xv.nc);
+      c->add_compress(m, l.xp, 1);
+      CHECK(c->exchange(m));
+      CHECK(launch_pull_v(c->stream, l, c->slots_u, eA, PH_OWNED));
+      CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, eM, PH_OWNED));
+    }
   }
   CHECK(c->sync());
   c->diag_ready = true;
@@ -1346,12 +1650,21 @@ int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const doub
     case AGMG_OP_A: return c->apply_level(0, l, cd, src, e);
     case AGMG_OP_MASS: return c->apply_level(1, l, cd, src, e);
     case AGMG_OP_STOKES: {
+      if (c->dist()) {
+        if (l != c->nl() - 1 || &cd != &c->active_coeff()) { set_error("distributed Stokes vmult: active mesh only"); return -2; }
+        return c->stokes_vmult(dst, src);
+      }
       CHECK(launch_op(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p, e, c->use_blocks));
       e.dst = dst + nu; e.x = src + nu;
       return launch_pull_p(c->stream, lv, c->slots_p, lv.dim, e);
     }
     default: {  // B^T: both blocks of dst are written (vmult zeroes dst first)
-      CHECK(launch_op(c->stream, lv, cd, AGMG_OP_BT, nullptr, src + nu, c->slots_u, nullptr, e, c->use_blocks));
+      if (c->dist()) {
+        if (l != c->nl() - 1 || &cd != &c->active_coeff()) { set_error("distributed B^T vmult: active mesh only"); return -2; }
+        CHECK(c->bt_residual(dst, nullptr, src + nu));
+      } else {
+        CHECK(launch_op(c->stream, lv, cd, AGMG_OP_BT, nullptr, src + nu, c->slots_u, nullptr, e, c->use_blocks));
+      }
       return vec_set(c->stream, dst + nu, 0.0, np);
     }
   }
@@ -1397,13 +1710,11 @@ static int transfer_host(agmg_ctx *c, int which, int fine_level, bool prolong, d
   int rc = c->h2d(ds, src, ns);
   if (!rc) rc = c->h2d(dd, dst, nd);
   if (!rc) {
-    if (prolong) rc = launch_prolongate_add(c->stream, F, C, vel, dd, ds);
+    if (prolong) rc = c->prolongate_from(vel ? 0 : 1, fine_level, dd, ds);
     else {
-      double *slots = vel ? c->slots_u : c->slots_p;
-      rc = launch_restrict_cells(c->stream, F, C, vel, ds, slots);
       EpiArgs e;
       e.epi = EPI_ADD; e.dst = dd;
-      if (!rc) rc = vel ? launch_pull_v(c->stream, C, slots, e) : launch_pull_p(c->stream, C, slots, 1, e);
+      rc = c->restrict_to(vel ? 0 : 1, fine_level, ds, e);
     }
   }
   if (!rc) rc = c->d2h(dst, dd, nd);
@@ -1474,6 +1785,7 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
   rep->setup_seconds = t_setup - t_begin;
   const DeviceLevel &lv = c->fin();
   const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p(), n = nu + np;
+  const agmg_ctx::Span sp = c->span_up();
   hipStream_t st = c->stream;
   // pool layout: 0..4 preconditioner scratch, 5 rhs, 6 x, 7 tmp, 8 x0, 9.. Krylov
   double *rhs, *x, *tmp, *x0;
@@ -1486,18 +1798,18 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
   if (!newton) {  // local_smoothing.cc:1132-1167
     CHECK(c->stokes_residual(tmp, rhs, x));
     double r0;
-    CHECK(c->norm(tmp, n, &r0));
+    CHECK(c->norm(tmp, sp, &r0));
     rep->initial_nonlinear_residual = r0;
     CHECK(vec_copy(st, x0, x, n));
     CHECK(vec_set(st, x0, 0.0, nu));
     CHECK(c->stokes_residual(tmp, rhs, x0));
     double d2[2];
-    CHECK(c->dots(tmp, {tmp}, nu, &d2[0]));
-    CHECK(c->dots(rhs + nu, {rhs + nu}, np, &d2[1]));
+    CHECK(c->dots(tmp, {tmp}, c->span_of(0, c->nl() - 1), &d2[0]));
+    CHECK(c->dots(rhs + nu, {rhs + nu}, c->span_of(1, c->nl() - 1), &d2[1]));
     tol = c->opt.linear_tolerance * std::sqrt(d2[0] + d2[1]);
   } else {  // :1169-1183
     double r0;
-    CHECK(c->norm(rhs, n, &r0));
+    CHECK(c->norm(rhs, sp, &r0));
     tol = c->opt.linear_tolerance * r0;
     rep->initial_nonlinear_residual = r0;
   }
@@ -1512,8 +1824,8 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
   const size_t pool0 = 9;
   c->nA = c->nS = 0;
   if (c->opt.n_cheap_steps > 0) {
-    if (c->opt.krylov_type == AGMG_KRYLOV_GMRES) CHECK(solver_gmres(c, Aop, Pc, x, rhs, n, c->opt.gmres_restart, cc, pool0, &state));
-    else CHECK(solver_idr(c, Aop, Pc, x, rhs, n, c->opt.idr_s, cc, pool0, &state));
+    if (c->opt.krylov_type == AGMG_KRYLOV_GMRES) CHECK(solver_gmres(c, Aop, Pc, x, rhs, sp, c->opt.gmres_restart, cc, pool0, &state));
+    else CHECK(solver_idr(c, Aop, Pc, x, rhs, sp, c->opt.idr_s, cc, pool0, &state));
   }
   nA_c = c->nA; nS_c = c->nS;
   rep->n_cheap_iterations = cc.last_step;
@@ -1522,7 +1834,7 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
     if (c->opt.n_expensive_steps == 0) status = 1;
     else {
       c->nA = c->nS = 0;
-      CHECK(solver_fgmres(c, Aop, Pe, x, rhs, n, c->opt.gmres_restart, ce, pool0, &state));
+      CHECK(solver_fgmres(c, Aop, Pe, x, rhs, sp, c->opt.gmres_restart, ce, pool0, &state));
       nA_e = c->nA; nS_e = c->nS;
       rep->n_expensive_iterations = ce.last_step;
       rep->final_linear_residual = ce.last_value;

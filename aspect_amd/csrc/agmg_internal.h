@@ -74,14 +74,33 @@ struct BlockTables {
   uint16_t *lidT = nullptr;       // [3^dim][cstride] local id (within its block) of each cell node
   uint32_t *sh_nodes = nullptr;   // [n_shared] global node
   uint32_t *sh_ptr = nullptr;     // [n_shared + 1]
-  uint32_t *sh_list = nullptr;    // slot positions, in block order
+  uint32_t *sh_list = nullptr;    // slot positions, in block order; positions >= n_shared_slots address
+                                  // the receive buffer of the ghost exchange (remote partial sums)
+  int n_shared_owned = 0;         // shared nodes [0, n_shared_owned) are owned, the rest ghosts
   size_t bytes = 0;
+};
+
+// Ghost exchange of one node space (Q2 velocity nodes or Q1 pressure nodes) of one level
+// (deal.II update_ghost_values / compress(add) of LinearAlgebra::distributed::Vector).
+// Ghost nodes sit behind the owned ones, grouped by owner rank; `send_nodes` lists per neighbour
+// the owned nodes it ghosts, in the order of its ghost group.
+struct Exchange {
+  int nc = 1;                      // values per node (dim for velocity, 1 for pressure)
+  int n_owned = 0, n_ghost = 0, n_export = 0;
+  std::vector<int> nbr, send_off, recv_off;   // node units; [n_nbr], [n_nbr+1], [n_nbr+1]
+  uint32_t *send_nodes = nullptr;  // device [n_export]
+  double *expbuf = nullptr;        // device [n_export*nc]: packed owner values out / remote partial sums in
+  double *ghostbuf = nullptr;      // device [n_ghost*nc]:  ghost partial sums out
+  bool active() const { return !nbr.empty(); }
 };
 
 struct DeviceLevel {
   bool set = false;
   int dim = 3;
   int n_cells = 0, n_nodes_v = 0, n_nodes_p = 0;
+  int n_owned_v = 0, n_owned_p = 0;  // owned nodes come first; == n_nodes_* on one rank
+  Exchange xv, xp;
+  uint32_t *gid_v = nullptr, *gid_p = nullptr;  // global node index of each local node (nullptr: identity)
   int cstride = 0;                 // padded cell count (SoA row stride)
   // SoA tables: [local index][cstride]
   uint32_t *cnvT = nullptr;        // [3^dim][cstride]: node | cmask << 29
@@ -133,14 +152,20 @@ int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
                       double *slots_p);
 int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u,
                       double *slots_p);
-int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e);
+// phase (distributed levels): PH_ALL everything at once (one rank); PH_GHOST the part before the
+// ghost exchange (cell phase + partial sums of ghost nodes into Exchange::ghostbuf); PH_OWNED the
+// part after it (sums of owned nodes including the received remote partial sums + epilogue)
+enum Phase { PH_ALL = 0, PH_GHOST = 1, PH_OWNED = 2 };
+int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e, int phase = PH_ALL);
 // Whole velocity-row application: cell phase + reduction + epilogue `eu` on the velocity rows.
 // Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.
 // Stokes pressure rows are left in slots_p for launch_pull_p(..., dim, ...).
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
-              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks);
+              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,
+              int phase = PH_ALL);
 // n_parts: partial values per (cell, i) slot (dim for the Stokes pressure rows, 1 for mass)
-int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e);
+int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e,
+                  int phase = PH_ALL);
 
 // ---- transfer (kernels_transfer.hip) ----
 int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
@@ -159,13 +184,18 @@ int vec_lincomb(hipStream_t s, double *dst, double a, const double *x, double b,
 int vec_pointwise_scale(hipStream_t s, double *dst, double f, const double *d, const double *b, size_t n);  // dst = f*d*b
 int vec_zero_constrained(hipStream_t s, double *x, const uint8_t *cmask, int n_nodes, int ncomp);
 int vec_fill_index_mod(hipStream_t s, double *x, size_t n, int mod);
+// x[node*nc + c] = (gid[node]*nc + c) % mod
+int vec_fill_gid_mod(hipStream_t s, double *x, const uint32_t *gid, int n_nodes, int nc, int mod);
+// out[k*nc + c] = x[nodes[k]*nc + c]
+int vec_gather_nodes(hipStream_t s, double *out, const double *x, const uint32_t *nodes, int n, int nc);
 int vec_shift(hipStream_t s, double *x, double a, size_t n);  // x += a
 constexpr int DOT_BLOCKS = 256;
 constexpr int DOT_MAX_VECS = 8;
 // out[k] = <x, ys[k]> for k < nvec <= DOT_MAX_VECS; result on device in `out`
 // (workspace `partials` holds DOT_BLOCKS*DOT_MAX_VECS doubles)
 struct VecPtrs { const double *p[DOT_MAX_VECS]; };
-int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n,
+// logical entry i lives at i (i < seg1) or i + gap: skips the ghost section of a block vector
+int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n, size_t seg1, size_t gap,
                   double *partials, double *out);
 struct Coeffs { double a[DOT_MAX_VECS]; };
 // y += sum_k a[k] * xs[k]

@@ -577,7 +577,10 @@ struct PullArgs {
   const uint32_t *ptr, *list;
   const double *slots;
   const uint8_t *cmask;
-  int n_nodes;
+  int node0, n_range;       // nodes [node0, node0 + n_range)
+  uint32_t recv_base;       // list entries >= recv_base address recv[(entry - recv_base) * NC + c]
+  const double *recv;       // remote partial sums (ghost exchange), or nullptr
+  double *ghost_out;        // != nullptr: raw sums to ghost_out[(node - node0) * NC + c], no epilogue
   EpiArgs e;
 };
 
@@ -615,19 +618,27 @@ __device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, cons
 // NC: components per node (one thread each); NPARTS: partial values per slot summed by the thread
 template <int NC, int NPARTS>
 __global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)P.n_nodes * NC) return;
-  const int node = (int)(t / NC), c = (int)(t - (long)node * NC);
+  const long tl = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tl >= (long)P.n_range * NC) return;
+  const int nl = (int)(tl / NC), c = (int)(tl - (long)nl * NC);
+  const int node = P.node0 + nl;
   const uint32_t s = P.ptr[node], en = P.ptr[node + 1];
   double sum = 0.0;
   for (uint32_t k = s; k < en; ++k) {
-    const size_t base = (size_t)P.list[k] * (NC * NPARTS) + c * NPARTS;
+    const uint32_t ent = P.list[k];
+    if (ent >= P.recv_base) {
+      sum += P.recv[(size_t)(ent - P.recv_base) * NC + c];
+    } else {
+      const size_t base = (size_t)ent * (NC * NPARTS) + c * NPARTS;
 #pragma unroll
-    for (int part = 0; part < NPARTS; ++part) sum += P.slots[base + part];
+      for (int part = 0; part < NPARTS; ++part) sum += P.slots[base + part];
+    }
   }
+  if (P.ghost_out) { P.ghost_out[tl] = sum; return; }
+  const size_t t = (size_t)node * NC + c;
   const bool con = P.cmask ? ((P.cmask[node] >> c) & 1u) : false;
   double out;
-  if (epi_value(P.e, (size_t)t, sum, con, out)) P.e.dst[t] = out;
+  if (epi_value(P.e, t, sum, con, out)) P.e.dst[t] = out;
 }
 
 // ---- block scatter: one workgroup = WAVES_PER_BLOCK batches of cells ("block").  Every lane
@@ -863,22 +874,34 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
 struct FixArgs {
   const uint32_t *sh_nodes, *sh_ptr, *sh_list;
   const double *slots_sh;
-  int n_shared;
+  int i0, n_range;          // shared nodes [i0, i0 + n_range)
+  uint32_t recv_base;       // sh_list entries >= recv_base address recv[(entry - recv_base) * NC + c]
+  const double *recv;
+  double *ghost_out;        // != nullptr: raw sums to ghost_out[(node - n_owned) * NC + c]
+  int n_owned;
   EpiArgs e;
 };
 template <int NC>
 __global__ void __launch_bounds__(256) k_fix(const FixArgs F) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= F.n_shared) return;
+  const int il = blockIdx.x * 256 + threadIdx.x;
+  if (il >= F.n_range) return;
+  const int i = F.i0 + il;
   const uint32_t s = F.sh_ptr[i], en = F.sh_ptr[i + 1];
   const uint32_t nd = F.sh_nodes[i];   // node | cmask << 29
   double sum[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) sum[c] = 0.0;
   for (uint32_t k = s; k < en; ++k) {
-    const double *p = F.slots_sh + (size_t)F.sh_list[k] * NC;
+    const uint32_t ent = F.sh_list[k];
+    const double *p = ent >= F.recv_base ? F.recv + (size_t)(ent - F.recv_base) * NC : F.slots_sh + (size_t)ent * NC;
 #pragma unroll
     for (int c = 0; c < NC; ++c) sum[c] += p[c];
+  }
+  if (F.ghost_out) {
+    double *o = F.ghost_out + (size_t)((int)(nd & NODE_MASK) - F.n_owned) * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[c] = sum[c];
+    return;
   }
   const size_t g0 = (size_t)(nd & NODE_MASK) * NC;
 #pragma unroll
@@ -1015,10 +1038,23 @@ int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
   return 0;
 }
 
-int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e) {
-  PullArgs p{L.pull_ptr_v, L.pull_list_v, slots, L.cmask_v, L.n_nodes_v, e};
-  const long n = (long)L.n_nodes_v * L.dim;
-  if (n <= 0) return 0;
+// node range and exchange buffers of one phase of a pull over a node space
+static bool pull_phase(PullArgs &p, const Exchange &x, int n_nodes, int n_owned, uint32_t recv_base, int phase) {
+  p.recv_base = 0xFFFFFFFFu; p.recv = nullptr; p.ghost_out = nullptr;
+  if (phase == PH_GHOST) {
+    p.node0 = n_owned; p.n_range = n_nodes - n_owned; p.ghost_out = x.ghostbuf;
+  } else {
+    p.node0 = 0; p.n_range = phase == PH_OWNED ? n_owned : n_nodes;
+    if (x.n_export > 0) { p.recv_base = recv_base; p.recv = x.expbuf; }
+  }
+  return p.n_range > 0;
+}
+
+int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e, int phase) {
+  PullArgs p{L.pull_ptr_v, L.pull_list_v, slots, L.cmask_v, 0, 0, 0, nullptr, nullptr, e};
+  const uint32_t recv_base = (uint32_t)((L.dim == 3 ? 27 : 9) * (size_t)L.cstride);
+  if (!pull_phase(p, L.xv, L.n_nodes_v, L.n_owned_v, recv_base, phase)) return 0;
+  const long n = (long)p.n_range * L.dim;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (L.dim == 3) hipLaunchKernelGGL((k_pull<3, 1>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((k_pull<2, 1>), grid, block, 0, s, p);
@@ -1026,10 +1062,12 @@ int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, cons
   return 0;
 }
 
-int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e) {
-  PullArgs p{L.pull_ptr_p, L.pull_list_p, slots, L.cmask_p, L.n_nodes_p, e};
-  const long n = L.n_nodes_p;
-  if (n <= 0) return 0;
+int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e,
+                  int phase) {
+  PullArgs p{L.pull_ptr_p, L.pull_list_p, slots, L.cmask_p, 0, 0, 0, nullptr, nullptr, e};
+  const uint32_t recv_base = (uint32_t)((L.dim == 3 ? 8 : 4) * (size_t)L.cstride);
+  if (!pull_phase(p, L.xp, L.n_nodes_p, L.n_owned_p, recv_base, phase)) return 0;
+  const long n = p.n_range;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (n_parts == 1) hipLaunchKernelGGL((k_pull<1, 1>), grid, block, 0, s, p);
   else if (n_parts == 2) hipLaunchKernelGGL((k_pull<1, 2>), grid, block, 0, s, p);
@@ -1040,16 +1078,31 @@ int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int 
 }
 
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
-              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks) {
+              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks, int phase) {
   if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB)) {
-    const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
-    if (rc) return rc;
-    return launch_pull_v(s, L, slots_u, eu);
+    if (phase != PH_OWNED) {
+      const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
+      if (rc) return rc;
+    }
+    return launch_pull_v(s, L, slots_u, eu, phase);
   }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
-  const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
   const BlockTables &bt = L.bt;
+  // fix-up over the shared nodes of one phase: ghosts -> Exchange::ghostbuf, owned -> dst (+ received sums)
+  auto fix = [&](int i0, int n_range, bool ghost) -> int {
+    if (n_range <= 0) return 0;
+    FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, i0, n_range, 0xFFFFFFFFu, nullptr, nullptr, L.n_owned_v, eu};
+    if (ghost) f.ghost_out = L.xv.ghostbuf;
+    else if (L.xv.n_export > 0) { f.recv_base = (uint32_t)bt.n_shared_slots; f.recv = L.xv.expbuf; }
+    const dim3 grid((unsigned)((n_range + 255) / 256)), block(256);
+    if (L.dim == 3) hipLaunchKernelGGL((k_fix<3>), grid, block, 0, s, f);
+    else hipLaunchKernelGGL((k_fix<2>), grid, block, 0, s, f);
+    AGMG_HIP_CHECK(hipGetLastError());
+    return 0;
+  };
+  if (phase == PH_OWNED) return fix(0, bt.n_shared_owned, false);
+  const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
   static unsigned long long *dbg_buf = nullptr;
 #if AGMG_ABLATE & 1024
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)4000000 * 8 * 8);
@@ -1085,15 +1138,8 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
             d[0] / nw, p1 / nw, p2 / nw, p3 / nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw);
   }
 #endif
-  if (bt.n_shared > 0) {
-    FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, bt.n_shared, eu};
-    const long n = (long)bt.n_shared;
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (L.dim == 3) hipLaunchKernelGGL((k_fix<3>), grid, block, 0, s, f);
-    else hipLaunchKernelGGL((k_fix<2>), grid, block, 0, s, f);
-    AGMG_HIP_CHECK(hipGetLastError());
-  }
-  return 0;
+  if (phase == PH_GHOST) return fix(bt.n_shared_owned, bt.n_shared - bt.n_shared_owned, true);
+  return fix(0, bt.n_shared, false);
 }
 
 }  // namespace agmg

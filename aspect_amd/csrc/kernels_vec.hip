@@ -53,11 +53,13 @@ __global__ void __launch_bounds__(VB) k_fill_mod(double *x, size_t n, int mod) {
 }
 
 template <int NV>
-__global__ void __launch_bounds__(VB) k_multi_dot(const double *x, VecPtrs ys, size_t n, double *partials) {
+__global__ void __launch_bounds__(VB) k_multi_dot(const double *x, VecPtrs ys, size_t n, size_t seg1, size_t gap,
+                                                  double *partials) {
   double acc[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+  for (size_t il = (size_t)blockIdx.x * VB + threadIdx.x; il < n; il += (size_t)gridDim.x * VB) {
+    const size_t i = il < seg1 ? il : il + gap;
     const double xv = x[i];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = fma(xv, ys.p[k][i], acc[k]);
@@ -92,6 +94,21 @@ __global__ void __launch_bounds__(DOT_BLOCKS) k_dot_final(const double *partials
     double s = 0.0;
     for (int w = 0; w < DOT_BLOCKS / 64; ++w) s += red[w];
     out[k] = s;
+  }
+}
+
+__global__ void __launch_bounds__(VB) k_fill_gid_mod(double *x, const uint32_t *gid, size_t n, int nc, int mod) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t node = i / nc;
+    const size_t c = i - node * nc;
+    x[i] = (double)(((size_t)gid[node] * nc + c) % mod);
+  }
+}
+__global__ void __launch_bounds__(VB) k_gather_nodes(double *out, const double *x, const uint32_t *nodes, size_t n, int nc) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t k = i / nc;
+    const size_t c = i - k * nc;
+    out[i] = x[(size_t)nodes[k] * nc + c];
   }
 }
 
@@ -135,22 +152,31 @@ int vec_zero_constrained(hipStream_t s, double *x, const uint8_t *cmask, int n_n
 int vec_shift(hipStream_t s, double *x, double a, size_t n) { LAUNCH_VEC(k_shift, n, x, a, n); }
 int vec_fill_index_mod(hipStream_t s, double *x, size_t n, int mod) { LAUNCH_VEC(k_fill_mod, n, x, n, mod); }
 
-int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n, double *partials,
-                  double *out) {
+int vec_fill_gid_mod(hipStream_t s, double *x, const uint32_t *gid, int n_nodes, int nc, int mod) {
+  const size_t n = (size_t)n_nodes * nc;
+  LAUNCH_VEC(k_fill_gid_mod, n, x, gid, n, nc, mod);
+}
+int vec_gather_nodes(hipStream_t s, double *out, const double *x, const uint32_t *nodes, int n_nodes, int nc) {
+  const size_t n = (size_t)n_nodes * nc;
+  LAUNCH_VEC(k_gather_nodes, n, out, x, nodes, n, nc);
+}
+
+int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n, size_t seg1, size_t gap,
+                  double *partials, double *out) {
   if (nvec < 1 || nvec > DOT_MAX_VECS) { set_error("vec_multi_dot: bad nvec"); return -1; }
   size_t g = (n + VB - 1) / VB;
   if (g > DOT_BLOCKS) g = DOT_BLOCKS;
   if (g < 1) g = 1;
   const dim3 grid((unsigned)g), block(VB);
   switch (nvec) {
-    case 1: hipLaunchKernelGGL((k_multi_dot<1>), grid, block, 0, s, x, ys, n, partials); break;
-    case 2: hipLaunchKernelGGL((k_multi_dot<2>), grid, block, 0, s, x, ys, n, partials); break;
-    case 3: hipLaunchKernelGGL((k_multi_dot<3>), grid, block, 0, s, x, ys, n, partials); break;
-    case 4: hipLaunchKernelGGL((k_multi_dot<4>), grid, block, 0, s, x, ys, n, partials); break;
-    case 5: hipLaunchKernelGGL((k_multi_dot<5>), grid, block, 0, s, x, ys, n, partials); break;
-    case 6: hipLaunchKernelGGL((k_multi_dot<6>), grid, block, 0, s, x, ys, n, partials); break;
-    case 7: hipLaunchKernelGGL((k_multi_dot<7>), grid, block, 0, s, x, ys, n, partials); break;
-    default: hipLaunchKernelGGL((k_multi_dot<8>), grid, block, 0, s, x, ys, n, partials); break;
+    case 1: hipLaunchKernelGGL((k_multi_dot<1>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    case 2: hipLaunchKernelGGL((k_multi_dot<2>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    case 3: hipLaunchKernelGGL((k_multi_dot<3>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    case 4: hipLaunchKernelGGL((k_multi_dot<4>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    case 5: hipLaunchKernelGGL((k_multi_dot<5>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    case 6: hipLaunchKernelGGL((k_multi_dot<6>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    case 7: hipLaunchKernelGGL((k_multi_dot<7>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    default: hipLaunchKernelGGL((k_multi_dot<8>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
   }
   hipLaunchKernelGGL(k_dot_final, dim3(nvec), dim3(DOT_BLOCKS), 0, s, partials, (int)g, out);
   AGMG_HIP_CHECK(hipGetLastError());

@@ -52,3 +52,125 @@ class Ranks:
 def aggregate_throughput(units_per_rank_step: float, steps: int, seconds_max: float, world: int) -> float:
     """whole-job units/s: units all ranks processed / max-over-ranks time (weak scaling)."""
     return world * units_per_rank_step * steps / seconds_max
+
+
+# ---------------------------------------------------------------------------------------------
+# Transport behind agmg_set_communicator (include/agmg.h): the library asks for two things only,
+# a neighbour exchange (ghost update / compress of one operator application) and a sum all-reduce
+# of a few scalars (dot products).  Here both go through torch.distributed: backend "nccl" (RCCL
+# over xGMI) on device pointers, ordered on the library's own HIP stream with no host
+# synchronisation; backend "gloo" on the host buffers the library stages when device_buffers = 0.
+# ---------------------------------------------------------------------------------------------
+import ctypes as C
+
+import numpy as np
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+class CommStruct(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("device_buffers", C.c_int32),
+                ("user", C.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN)]
+
+
+class _DevView:
+    """Minimal __cuda_array_interface__ carrier: lets torch wrap a raw device pointer."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def exchange_host(dist, torch, msgs):
+    """msgs: list of (peer, send ndarray | None, recv ndarray | None); non-blocking pairs, then wait."""
+    ops, keep = [], []
+    for peer, snd, rcv in msgs:
+        if snd is not None and snd.size:
+            t = torch.from_numpy(snd)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer))
+        if rcv is not None and rcv.size:
+            t = torch.from_numpy(rcv)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+class Transport:
+    """Owns the C callbacks (keeps them alive) for one Ranks group."""
+
+    def __init__(self, ranks: Ranks):
+        self.r = ranks
+        self.torch, self.dist = ranks.torch, ranks.dist
+        self.device_buffers = 1 if ranks.backend == "nccl" else 0
+        self._views = {}
+        self._streams = {}
+        self.n_exchange = self.n_allreduce = 0
+        self._ex = EXCHANGE_FN(self._exchange)
+        self._ar = ALLREDUCE_FN(self._allreduce)
+        self.struct = CommStruct(ranks.rank, ranks.world, self.device_buffers, None, self._ex, self._ar)
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _dev(self, ptr, n):
+        key = (ptr, n)
+        t = self._views.get(key)
+        if t is None:
+            t = self.torch.as_tensor(_DevView(ptr, n), device=self.r.device)
+            self._views[key] = t
+        return t
+
+    def _stream(self, handle):
+        s = self._streams.get(handle)
+        if s is None:
+            s = self.torch.cuda.ExternalStream(handle, device=self.r.device)
+            self._streams[handle] = s
+        return s
+
+    # -- callbacks ----------------------------------------------------------------------------
+    def _exchange(self, user, n, peer, send, n_send, recv, n_recv, stream):
+        try:
+            self.n_exchange += 1
+            if self.device_buffers:
+                dist = self.dist
+                with self.torch.cuda.stream(self._stream(stream)):
+                    ops = []
+                    for i in range(n):
+                        if n_send[i] > 0:
+                            ops.append(dist.P2POp(dist.isend, self._dev(send[i], n_send[i]), peer[i]))
+                        if n_recv[i] > 0:
+                            ops.append(dist.P2POp(dist.irecv, self._dev(recv[i], n_recv[i]), peer[i]))
+                    if ops:
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()      # stream-ordered: makes `stream` wait for the transfers
+            else:
+                msgs = []
+                for i in range(n):
+                    snd = np.ctypeslib.as_array(C.cast(send[i], C.POINTER(C.c_double)), (n_send[i],)) if n_send[i] > 0 else None
+                    rcv = np.ctypeslib.as_array(C.cast(recv[i], C.POINTER(C.c_double)), (n_recv[i],)) if n_recv[i] > 0 else None
+                    msgs.append((peer[i], snd, rcv))
+                exchange_host(self.dist, self.torch, msgs)
+            return 0
+        except Exception as e:  # never let an exception cross the C ABI
+            import sys
+            print(f"[aspect_amd transport] exchange failed on rank {self.r.rank}: {e!r}", file=sys.stderr, flush=True)
+            return -1
+
+    def _allreduce(self, user, values, n, stream):
+        try:
+            self.n_allreduce += 1
+            if self.device_buffers:
+                with self.torch.cuda.stream(self._stream(stream)):
+                    self.dist.all_reduce(self._dev(values, n), op=self.dist.ReduceOp.SUM)
+            else:
+                a = np.ctypeslib.as_array(C.cast(values, C.POINTER(C.c_double)), (n,))
+                self.dist.all_reduce(self.torch.from_numpy(a), op=self.dist.ReduceOp.SUM)
+            return 0
+        except Exception as e:
+            import sys
+            print(f"[aspect_amd transport] all-reduce failed on rank {self.r.rank}: {e!r}", file=sys.stderr, flush=True)
+            return -1

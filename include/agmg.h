@@ -74,12 +74,41 @@ typedef struct agmg_options {
   double  coarse_range;          /* 1e-3 */
   int32_t coarse_eig_cg_n_iterations; /* 100 */
   int32_t schur_smoother_steps;  /* mg_smoother_Schur(4) */
-  /* multi-GPU: world size/rank of this context and an opaque 128-byte RCCL
-   * unique id shared by all ranks (ignored when world_size == 1) */
+  /* multi-GPU: world size/rank of this context (one rank <-> one GPU <-> one
+   * subdomain).  world_size > 1 needs agmg_set_communicator before any table is
+   * set.  nccl_id is reserved (an in-library RCCL transport would take its
+   * unique id here); it is ignored today. */
   int32_t world_size;
   int32_t rank;
   uint8_t nccl_id[128];
 } agmg_options;
+
+/* Transport of a distributed context.  The reference runs this path over MPI
+ * (LinearAlgebra::distributed::Vector::update_ghost_values / compress and
+ * MPI_Allreduce inside deal.II's vector dot products); the
+ * library needs exactly those two operations and takes them as callbacks so the
+ * host can bind whatever it runs on: RCCL through torch.distributed
+ * (aspect_amd/parallel.py), GPU-aware MPI in the ASPECT glue.
+ *   exchange: n_msgs pairwise messages; message i sends n_send[i] doubles from
+ *     send[i] to rank peer[i] and receives n_recv[i] doubles from it into
+ *     recv[i] (either count may be 0).  Both sides list their messages to each
+ *     other in the same order.
+ *   allreduce_sum: in-place sum over all ranks of n doubles.
+ * device_buffers = 1: pointers are device memory and the callback must order
+ *   its work after everything already enqueued on `stream` and make later work
+ *   on `stream` wait for it (no host synchronisation needed);
+ * device_buffers = 0: the library stages through pinned host memory, the
+ *   pointers are host memory, `stream` is NULL and the callback blocks.
+ * Return 0 on success. */
+typedef struct agmg_comm {
+  int32_t rank, size;
+  int32_t device_buffers;
+  void *user;
+  int (*exchange)(void *user, int32_t n_msgs, const int32_t *peer,
+                  const double *const *send, const int64_t *n_send,
+                  double *const *recv, const int64_t *n_recv, void *stream);
+  int (*allreduce_sum)(void *user, double *values, int32_t n, void *stream);
+} agmg_comm;
 
 void agmg_default_options(agmg_options *opt);
 
@@ -114,6 +143,11 @@ typedef struct agmg_level_desc {
   const int32_t *send_offsets_p;
   const uint32_t *send_nodes_p;
   const int32_t *recv_offsets_p;
+  /* global index of every local node (world_size > 1; NULL = the local index).
+   * Only used for the start vector of the Chebyshev eigenvalue estimate
+   * (SURVEY.md A.5), so that it does not depend on the partition. */
+  const uint32_t *global_nodes_v; /* [n_nodes_v] */
+  const uint32_t *global_nodes_p; /* [n_nodes_p] */
 } agmg_level_desc;
 
 /* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */
@@ -154,6 +188,17 @@ const char *agmg_last_error(void);
 /* create_matrix_free_solver + constructor (stokes_matrix_free.cc:29-62) */
 agmg_ctx *agmg_create(const agmg_options *opt);
 void      agmg_destroy(agmg_ctx *ctx);
+
+/* Bind the transport of a distributed context (opt.world_size > 1); the struct
+ * is copied, the callbacks and `user` must outlive the context.  Replaces the
+ * MPI communicator the reference takes from SimulatorAccess
+ * (get_mpi_communicator(), used throughout local_smoothing.cc).  In a
+ * distributed context every vector crossing this ABI is the rank-LOCAL vector
+ * (owned entries first, ghost entries behind them, as in agmg_level_desc):
+ * owned entries of inputs must be valid, ghost entries are refreshed
+ * internally (the library writes them, also in `src` arguments on the
+ * device); only owned entries of outputs are meaningful. */
+int agmg_set_communicator(agmg_ctx *ctx, const agmg_comm *comm);
 
 /* setup_dofs(): upload the tables of one level (local_smoothing.cc:1548-1878).
  * level in [0, n_levels) or AGMG_ACTIVE. desc == NULL for AGMG_ACTIVE aliases
