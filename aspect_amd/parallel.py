@@ -104,10 +104,13 @@ def exchange_host(dist, torch, msgs):
 class Transport:
     """Owns the C callbacks (keeps them alive) for one Ranks group."""
 
-    def __init__(self, ranks: Ranks):
+    def __init__(self, ranks: Ranks, device_buffers=None):
         self.r = ranks
         self.torch, self.dist = ranks.torch, ranks.dist
-        self.device_buffers = 1 if ranks.backend == "nccl" else 0
+        # gloo with device_buffers = 1 (tests on one GPU): this class stages the device buffers
+        # through host tensors itself, exercising the library's device-pointer protocol
+        self.device_buffers = (1 if ranks.backend == "nccl" else 0) if device_buffers is None else int(device_buffers)
+        self.on_device_wire = ranks.backend == "nccl"
         self._views = {}
         self._streams = {}
         self.n_exchange = self.n_allreduce = 0
@@ -138,15 +141,28 @@ class Transport:
             if self.device_buffers:
                 dist = self.dist
                 with self.torch.cuda.stream(self._stream(stream)):
-                    ops = []
-                    for i in range(n):
-                        if n_send[i] > 0:
-                            ops.append(dist.P2POp(dist.isend, self._dev(send[i], n_send[i]), peer[i]))
-                        if n_recv[i] > 0:
-                            ops.append(dist.P2POp(dist.irecv, self._dev(recv[i], n_recv[i]), peer[i]))
-                    if ops:
-                        for req in dist.batch_isend_irecv(ops):
-                            req.wait()      # stream-ordered: makes `stream` wait for the transfers
+                    if self.on_device_wire:
+                        ops = []
+                        for i in range(n):
+                            if n_send[i] > 0:
+                                ops.append(dist.P2POp(dist.isend, self._dev(send[i], n_send[i]), peer[i]))
+                            if n_recv[i] > 0:
+                                ops.append(dist.P2POp(dist.irecv, self._dev(recv[i], n_recv[i]), peer[i]))
+                        if ops:
+                            for req in dist.batch_isend_irecv(ops):
+                                req.wait()      # stream-ordered: makes `stream` wait for the transfers
+                    else:
+                        msgs, back = [], []
+                        for i in range(n):
+                            snd = self._dev(send[i], n_send[i]).cpu().numpy() if n_send[i] > 0 else None
+                            rcv = np.zeros(n_recv[i]) if n_recv[i] > 0 else None
+                            msgs.append((peer[i], snd, rcv))
+                            if rcv is not None:
+                                back.append((self._dev(recv[i], n_recv[i]), rcv))
+                        exchange_host(self.dist, self.torch, msgs)
+                        for t, rcv in back:
+                            t.copy_(self.torch.from_numpy(rcv))
+                        self.torch.cuda.current_stream().synchronize()
             else:
                 msgs = []
                 for i in range(n):
@@ -165,7 +181,14 @@ class Transport:
             self.n_allreduce += 1
             if self.device_buffers:
                 with self.torch.cuda.stream(self._stream(stream)):
-                    self.dist.all_reduce(self._dev(values, n), op=self.dist.ReduceOp.SUM)
+                    t = self._dev(values, n)
+                    if self.on_device_wire:
+                        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                    else:
+                        h = t.cpu()
+                        self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+                        t.copy_(h)
+                        self.torch.cuda.current_stream().synchronize()
             else:
                 a = np.ctypeslib.as_array(C.cast(values, C.POINTER(C.c_double)), (n,))
                 self.dist.all_reduce(self.torch.from_numpy(a), op=self.dist.ReduceOp.SUM)

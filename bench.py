@@ -6,9 +6,11 @@ Stokes-solve time (3-D Q2-Q1), beside the CPU oracle timed on the host cores.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one StokesOperator::vmult (matrix_free_operators.cc:171-278 + deal.II wrapper) on the
-workload's active mesh with all inputs resident in HBM.  value = (velocity + pressure DoFs of all
-ranks) / time per step.  N > 1: every rank owns one GPU and an identical subdomain-sized problem
-(weak scaling); ghost exchange between subdomains is not built yet, so ranks are
+workload's active mesh with all inputs resident in HBM.  value = (velocity + pressure DoFs of the
+whole job) / time per step.  N > 1 (weak scaling): the domain is N unit cubes (2x1x1, 2x2x1,
+2x2x2), one per rank/GPU, each refined like the N = 1 workload; every vmult updates the ghost
+values and compresses the interface sums over RCCL (aspect_amd/parallel.py Transport behind
+agmg_set_communicator).  Should the distributed set-up fail on a node, the ranks fall back to
 independent replicas and the line says so in config.parallelism.
 """
 import argparse
@@ -57,9 +59,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal knob for a one-GPU box: AGMG_BENCH_BACKEND=gloo lets N ranks share cuda:0 (RCCL
+    # refuses two ranks on one device); the driver's multi-GPU runs use the default, RCCL
+    backend = os.environ.get("AGMG_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    ranks = Ranks(backend=backend, device=dev)
     rank, world = ranks.rank, ranks.world
 
     from aspect_amd import capi, cases
@@ -67,13 +73,55 @@ def main():
     barrier, max_over_ranks = ranks.barrier, ranks.max_over_ranks
 
     # ---------------------------------------------------------------- workload (configs[1])
-    prob = cases.convection_box(3, args.refinement).build()
-    solver = capi.Solver(lib, prob, device=local_rank)
-    fin = prob.hier.finest
-    nu, npd = fin.n_dofs_v, fin.n_dofs_p
+    def serial_setup():
+        prob = cases.convection_box(3, args.refinement).build()
+        solver = capi.Solver(lib, prob, device=local_rank)
+        fin = prob.hier.finest
+        src_h = np.sin(0.37 * np.arange(fin.n_dofs_v + fin.n_dofs_p))
+        src_h[:fin.n_dofs_v][fin.constrained_dofs_v()] = 0.0
+        return prob, solver, fin, src_h, fin.n_dofs_v, fin.n_dofs_p
+
+    def distributed_setup():
+        from aspect_amd import partition
+        from aspect_amd.parallel import Transport
+        reps = {2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}.get(world)
+        if reps is None:
+            raise ValueError(f"no subdomain layout for {world} ranks")
+        g = cases.convection_box(3, args.refinement)
+        g.reps, g.extents = reps, [float(r) for r in reps]
+        g.build()
+        loc = partition.LocalProblem(g, rank, world)
+        tr = Transport(ranks)
+        solver = capi.Solver(lib, loc, transport=tr, device=local_rank)
+        gf = g.hier.finest
+        src_g = np.sin(0.37 * np.arange(gf.n_dofs_v + gf.n_dofs_p))
+        src_g[:gf.n_dofs_v][gf.constrained_dofs_v()] = 0.0
+        # whole-job DoFs / N = DoFs per GPU (owned)
+        return loc, solver, loc.hier.finest, loc.to_local(src_g), gf.n_dofs_v / world, gf.n_dofs_p / world
+
+    parallelism = "1 rank"
+    if world > 1:
+        failed, err = 0.0, ""
+        try:
+            prob, solver, fin, src_h, nu, npd = distributed_setup()
+            src = torch.from_numpy(src_h).to(dev)
+            dst = torch.empty_like(src)
+            if lib.vmult_device(solver.ctx, capi.OP_STOKES, capi.ACTIVE, dst.data_ptr(), src.data_ptr()):
+                raise RuntimeError(lib.last_error().decode())
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            failed, err = 1.0, repr(e)
+        if max_over_ranks(failed) > 0:
+            if rank == 0:
+                print(f"[bench] distributed set-up failed ({err}); running independent replicas", file=sys.stderr)
+            prob, solver, fin, src_h, nu, npd = serial_setup()
+            parallelism = f"{world} independent subdomain replicas (distributed set-up failed on this node)"
+        else:
+            parallelism = (f"{world} subdomains (one unit cube per GPU), ghost update + compress per vmult and "
+                           f"all-reduce per dot product over RCCL (torch.distributed)")
+    else:
+        prob, solver, fin, src_h, nu, npd = serial_setup()
     n = nu + npd
-    src_h = np.sin(0.37 * np.arange(n))
-    src_h[:nu][fin.constrained_dofs_v()] = 0.0
     src = torch.from_numpy(src_h).to(dev)
     dst = torch.empty_like(src)
 
@@ -115,7 +163,7 @@ def main():
              "solve_seconds": solve_s, "solve_setup_seconds": rep.setup_seconds,
              "gmres_iterations": f"{rep2.n_cheap_iterations}+{rep2.n_expensive_iterations}",
              "vcycles_A": rep2.n_A_preconditioner_cheap, "vcycles_S": rep2.n_S_preconditioner_cheap,
-             "solve_status": rc, "velocity_dofs": nu, "pressure_dofs": npd}
+             "solve_status": rc, "velocity_dofs": int(world * nu), "pressure_dofs": int(world * npd)}
     solver.close()
 
     # ---------------------------------------------------------------- chip-filling level
@@ -155,8 +203,8 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                 "data": "synthetic",
                 "config": {"workload": f"cookbooks/convection_box_3d, global refinement {args.refinement}, "
-                                       f"{fin.n_cells} cells, {nu}+{npd} DoFs per GPU, per-q viscosity tables",
-                           "parallelism": "1 rank" if world == 1 else f"{world} independent subdomain replicas (no ghost exchange yet)"},
+                                       f"{fin.n_cells} cells, {int(nu)}+{int(npd)} DoFs per GPU, per-q viscosity tables",
+                           "parallelism": parallelism},
                 "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, **extra}
         print(json.dumps(line))
     ranks.close()

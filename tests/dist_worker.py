@@ -5,8 +5,9 @@ Every rank owns one subdomain of the same global problem, runs the HIP library o
 with the ghost exchange / all-reduce going through aspect_amd.parallel.Transport, and compares the
 OWNED entries of every result with the serial CPU oracle applied to the GLOBAL problem.
 
-usage: dist_worker.py <case> <backend: gloo|nccl> [what: all|vmult]
-All ranks may share one GPU (gloo: the library stages messages through host memory)."""
+usage: dist_worker.py <case> <backend: gloo|nccl|gloo-dev> [what: all|vmult]
+All ranks may share one GPU (gloo: the library stages messages through host memory; gloo-dev: the
+library hands out device pointers as it does for RCCL and the transport stages them itself)."""
 import os
 import sys
 
@@ -55,8 +56,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local_rank % max(n_gpu, 1))
     torch.cuda.set_device(dev)
-    ranks = parallel.Ranks(backend=backend, device=dev)
-    tr = parallel.Transport(ranks)
+    ranks = parallel.Ranks(backend=backend.split("-")[0], device=dev)
+    tr = parallel.Transport(ranks, device_buffers=1 if backend == "gloo-dev" else None)
     g = global_problem(case, ranks.world)
     loc = partition.LocalProblem(g, ranks.rank, ranks.world)
     hip = capi.Solver(capi.load(), loc, transport=tr, device=dev.index)

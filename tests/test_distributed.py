@@ -60,7 +60,18 @@ def test_world_size_2_gloo_partition_and_transport():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,case", [(2, "nsinker"), (4, "nsinker_harmonic"), (8, "box3d"), (2, "deformed"), (4, "box2d")])
-def test_distributed_hip_matches_serial_oracle(nproc, case):
-    out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, "gloo", "all"], 29550 + nproc)
+@pytest.mark.parametrize("nproc,case,wire", [(2, "nsinker", "gloo"), (4, "nsinker_harmonic", "gloo"), (8, "box3d", "gloo"),
+                                             (2, "deformed", "gloo"), (4, "box2d", "gloo"),
+                                             # device-pointer protocol of the communicator (what RCCL uses)
+                                             (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
+def test_distributed_hip_matches_serial_oracle(nproc, case, wire):
+    out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, wire, "all"], 29550 + nproc)
     assert "[dist]" in out
+
+
+@pytest.mark.gpu
+def test_transport_device_callbacks_on_a_one_rank_rccl_group():
+    """The RCCL leg of aspect_amd.parallel.Transport on the one GPU a test box has: a 1-rank
+    "nccl" group; the all-reduce callback gets a raw device pointer and the library-stream handle."""
+    out = _launch(1, [os.path.join("tests", "dist_nccl1_worker.py")], 29549)
+    assert "[nccl1] ok" in out
