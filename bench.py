@@ -42,6 +42,19 @@ def algorithmic_bytes_per_cell(nqv, stokes=False):
 A_FLOP_PER_CELL = 6800.0     # ~6.8 kflop/cell, Cartesian
 
 
+def measured_traffic(refinement, n_cells):
+    """HBM bytes per A-block vmult from the committed PMC passes (profiles/r1_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc.sh, gfx950 correction 2 x FETCH_SIZE,
+    calibrated in profiles/r1_fetch_size_calibration.txt).  bench.py cannot run rocprofv3 on itself,
+    so the number is the last committed measurement of this same workload, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            e = json.load(f)["convection_box_3d"].get(str(refinement))
+        return float(e["traffic_bytes"]) if e and e["n_cells"] == n_cells else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +162,9 @@ def main():
     bytes_A = fin.n_cells * algorithmic_bytes_per_cell(nqv)
     roof = {"kernel": "A-block vmult = k_cells_blk<A> + k_fix (ABlockOperator::vmult)", "bound": "hbm",
             "achieved": bytes_A / t_A / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": bytes_A / t_A / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": bytes_A / t_A / 1e9 / HBM_PEAK_GBS,
+            "traffic": measured_traffic(args.refinement, fin.n_cells) if world == 1 else None,
+            "algorithmic_bytes": bytes_A,
             "us_per_launch": 1e6 * t_A, "gdofs": nu / t_A / 1e9,
             "fp64_frac": fin.n_cells * A_FLOP_PER_CELL / t_A / 1e12 / FP64_PEAK_TFLOPS,
             "bytes_per_cell": algorithmic_bytes_per_cell(nqv)}
@@ -178,6 +193,7 @@ def main():
         roof_large = {"workload": f"convection_box_3d r{args.large_refinement} ({fl.n_cells} cells, {fl.n_dofs_v} velocity DoFs)",
                       "achieved": bl / tl / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bl / tl / 1e9 / HBM_PEAK_GBS, "us_per_launch": 1e6 * tl,
+                      "traffic": measured_traffic(args.large_refinement, fl.n_cells), "algorithmic_bytes": bl,
                       "gdofs": fl.n_dofs_v / tl / 1e9,
                       "fp64_frac": fl.n_cells * A_FLOP_PER_CELL / tl / 1e12 / FP64_PEAK_TFLOPS}
         sl.close()
