@@ -221,6 +221,11 @@ struct agmg_ctx {
   }
 
   bool use_blocks = true;
+  bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
+  // Chebyshev coefficient sequences of cheb_vmult / cheb_step as a program for the fused kernels
+  void program_vmult(const Smoother &s, SmootherProgram &p) const;
+  void program_step(const Smoother &s, SmootherProgram &p) const;
+  bool fused_mass(int l) const { return use_fused && L[l].mass_fusable; }
   void free_level(DeviceLevel &l);
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                          const std::vector<uint32_t> &send_nodes);
@@ -749,15 +754,49 @@ int agmg_ctx::cheb_step(int which, int l, double *&x, double *&xo, const double 
   return 0;
 }
 
+void agmg_ctx::program_vmult(const Smoother &s, SmootherProgram &p) const {
+  p.s[p.n++] = {0.0, 1.0 / s.theta, SM_POINTWISE, 0};
+  if (s.degree < 2 || std::fabs(s.delta) < 1e-40) return;
+  double rhok = s.delta / s.theta;
+  const double sigma = s.theta / s.delta;
+  for (int k = 0; k < s.degree - 1; ++k) {
+    const double rhokp = 1.0 / (2.0 * sigma - rhok);
+    p.s[p.n++] = {rhokp * rhok, 2.0 * rhokp / s.delta, SM_CHEB, k == 0 ? 0 : 1};
+    rhok = rhokp;
+  }
+}
+void agmg_ctx::program_step(const Smoother &s, SmootherProgram &p) const {
+  p.s[p.n++] = {0.0, 1.0 / s.theta, SM_CHEB, 0};
+  if (s.degree < 2 || std::fabs(s.delta) < 1e-40) return;
+  double rhok = s.delta / s.theta;
+  const double sigma = s.theta / s.delta;
+  for (int k = 0; k < s.degree - 1; ++k) {
+    const double rhokp = 1.0 / (2.0 * sigma - rhok);
+    p.s[p.n++] = {rhokp * rhok, 2.0 * rhokp / s.delta, SM_CHEB, 1};
+    rhok = rhokp;
+  }
+}
+
 // mg::SmootherRelaxation(steps): apply = vmult + (steps-1) step; smooth = steps x step
 int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
+    SmootherProgram p;
+    program_vmult(sm[1][l], p);
+    for (int i = 1; i < steps; ++i) program_step(sm[1][l], p);
+    return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, nullptr, mg_sol[1][l], nullptr);
+  }
   CHECK(cheb_vmult(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   for (int i = 1; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   return 0;
 }
 int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
+    SmootherProgram p;
+    for (int i = 0; i < steps; ++i) program_step(sm[1][l], p);
+    return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, mg_sol[1][l], mg_sol[1][l], nullptr);
+  }
   for (int i = 0; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   return 0;
 }
@@ -814,11 +853,21 @@ int agmg_ctx::coarse_solve(int which) {
 int agmg_ctx::level_v_step(int which, int l) {
   if (l == 0) return coarse_solve(which);
   const DeviceLevel &F = L[l];
+  const int sm_steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  if (which == 1 && fused_mass(l) && sm_steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
+    // pre-smoothing and the residual behind it in one launch
+    SmootherProgram p;
+    program_vmult(sm[1][l], p);
+    for (int i = 1; i < sm_steps; ++i) program_step(sm[1][l], p);
+    p.s[p.n++] = {0.0, 0.0, SM_RESID, 0};
+    CHECK(launch_mass_smoother(stream, F, F.coeff, p, F.inv_diag_M, mg_def[1][l], nullptr, mg_sol[1][l], mg_t[1][l]));
+  } else {
   CHECK(smoother_apply(which, l, mg_def[which][l]));
   {  // t = defect - A solution
     EpiArgs e;
     e.epi = EPI_RESID; e.dst = mg_t[which][l]; e.b = mg_def[which][l];
     CHECK(apply_level(which, l, F.coeff, mg_sol[which][l], e));
+  }
   }
   {  // defect[l-1] = R t   (coarse Dirichlet rows dropped)
     EpiArgs e;
@@ -1368,6 +1417,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   auto *c = new agmg_ctx();
   c->opt = *opt;
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   c->L.resize(opt->n_levels);
   c->H.resize(opt->n_levels);
   for (int w = 0; w < 2; ++w) c->send_nodes_h[w].resize(opt->n_levels);
@@ -1510,6 +1560,12 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
         list[fill[node]++] = (uint32_t)((size_t)a * cs + cell);
       }
     for (size_t k = 0; k < snh.size(); ++k) list[fill[snh[k]]++] = (uint32_t)((size_t)nloc * cs + k);
+    if (!vel) {
+      uint32_t max_val = 0;
+      for (int i = 0; i < nn; ++i) max_val = std::max(max_val, ptr[i + 1] - ptr[i]);
+      lv.mass_fusable = !c->dist() && lv.n_cells <= MS_THREADS && (size_t)lv.n_cells * nloc <= (size_t)MS_MAX_SLOTS &&
+                        nn <= MS_MAX_NODES && max_val <= 8;
+    }
     if (vel) { CHECK(c->upload(&lv.cnvT, T)); CHECK(c->upload(&lv.pull_ptr_v, ptr)); CHECK(c->upload(&lv.pull_list_v, list)); CHECK(c->upload(&lv.cmask_v, cmv)); }
     else { CHECK(c->upload(&lv.cnpT, T)); CHECK(c->upload(&lv.pull_ptr_p, ptr)); CHECK(c->upload(&lv.pull_list_p, list)); CHECK(c->upload(&lv.cmask_p, cmp)); }
     lv.bytes_tables += (T.size() + ptr.size() + list.size()) * 4;

@@ -127,6 +127,7 @@ struct DeviceLevel {
   double *inv_mult_v = nullptr, *inv_mult_p = nullptr;
   uint32_t *childrenT = nullptr;   // [2^dim][cstride of level-1]: child cell ids on this level
   bool has_transfer = false;
+  bool mass_fusable = false;       // the level fits the one-workgroup fused mass smoother
   size_t bytes_tables = 0, bytes_transfer = 0, bytes_constraints = 0;
   int n_dofs_v() const { return dim * n_nodes_v; }
   int n_dofs_p() const { return n_nodes_p; }
@@ -166,6 +167,20 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
 // n_parts: partial values per (cell, i) slot (dim for the Stokes pressure rows, 1 for mass)
 int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e,
                   int phase = PH_ALL);
+
+// ---- fused Chebyshev smoother of the Schur-complement mass operator on small levels -----------
+// One workgroup runs a whole mg::SmootherRelaxation sequence (every Chebyshev step of every
+// smoothing step, optionally the residual behind it) in ONE launch: per-cell coefficients and the
+// node's vector entries stay in registers, the iterate lives in LDS.  The same arithmetic as the
+// unfused path (k_mass + k_pull + epilogue), step by step.
+struct SmootherStep { double f1, f2; int kind, use_xold; };   // kind: SM_POINTWISE x = f2*dinv*b | SM_CHEB | SM_RESID
+enum { SM_POINTWISE = 0, SM_CHEB = 1, SM_RESID = 2 };
+constexpr int SM_MAX_STEPS = 40;
+struct SmootherProgram { int n = 0; SmootherStep s[SM_MAX_STEPS]; };
+constexpr int MS_THREADS = 1024, MS_MAX_SLOTS = 4096, MS_MAX_NODES = 768;
+// x_in == nullptr: the program starts with SM_POINTWISE; resid_out receives b - M x of an SM_RESID step
+int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SmootherProgram &prog,
+                         const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out);
 
 // ---- transfer (kernels_transfer.hip) ----
 int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,

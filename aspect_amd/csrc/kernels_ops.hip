@@ -506,6 +506,127 @@ __global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
   for (int b = 0; b < NP; ++b) A.slots_p[(size_t)b * cs + cell] = pout[b];
 }
 
+// ---- fused Chebyshev smoother of the mass operator, one workgroup (agmg_internal.h) ----------
+struct MassSmArgs {
+  const uint32_t *ptr, *list;
+  const uint8_t *cmask;
+  const double *dinv, *b, *x_in;
+  double *x_out, *resid_out;
+  int n_nodes;
+};
+template <int DIM, bool PERQ, bool GEN>
+__global__ void __launch_bounds__(MS_THREADS) k_mass_smoother(const CellArgs A, const MassSmArgs M, const SmootherProgram P) {
+  constexpr int NP = (DIM == 3) ? 8 : 4;
+  constexpr int NQ = (DIM == 3) ? 27 : 9;
+  __shared__ double slots[MS_MAX_SLOTS];
+  __shared__ double X[MS_MAX_NODES];
+  const int t = threadIdx.x;
+  const size_t cs = (size_t)A.cstride;
+  const int CS = A.n_cells;   // slot row stride
+  const bool is_cell = t < A.n_cells, is_node = t < M.n_nodes;
+  // cell role: node indices and quadrature coefficients of my cell, kept in registers
+  uint32_t idx[NP];
+  constexpr bool TAB = PERQ || GEN;      // a coefficient per q-point (else weight * one cell factor)
+  double coef[TAB ? NQ : 1];
+  double scale = 0.0, ie_c = 0.0;
+  if (is_cell) {
+#pragma unroll
+    for (int b = 0; b < NP; ++b) idx[b] = A.cnpT[b * cs + t];
+    double det = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) det *= GEN ? 1.0 : A.hT[d * cs + t];
+    scale = A.lambda * A.lambda * det;
+    ie_c = PERQ ? 1.0 : 1.0 / A.etaT[t];
+    if (TAB) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+        const double wq = wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
+        const double ie = PERQ ? 1.0 / A.etaT[(size_t)q * cs + t] : ie_c;
+        coef[q] = (GEN ? A.jxwT[(size_t)q * cs + t] : wq) * scale * ie;   // product order of k_mass
+      }
+    }
+  }
+  // node role: my row of the pull CSR (as LDS slot indices) and my vector entries
+  int ent[8], cnt = 0;
+  double x = 0.0, xo = 0.0, bv = 0.0, dv = 0.0;
+  bool con = false;
+  if (is_node) {
+    const uint32_t s0 = M.ptr[t];
+    cnt = (int)(M.ptr[t + 1] - s0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ent[k] = 0;
+      if (k < cnt) {
+        const uint32_t e = M.list[s0 + k];
+        const uint32_t a = e / (uint32_t)cs;
+        ent[k] = (int)(a * CS + (e - a * (uint32_t)cs));
+      }
+    }
+    bv = M.b[t];
+    dv = M.dinv[t];
+    con = M.cmask ? (M.cmask[t] & 1u) : false;
+    if (M.x_in) x = M.x_in[t];
+    X[t] = x;
+  }
+  __syncthreads();
+  for (int st = 0; st < P.n; ++st) {
+    const SmootherStep S = P.s[st];
+    if (S.kind == SM_POINTWISE) {
+      if (is_node) { x = S.f2 * dv * bv; X[t] = x; }
+      __syncthreads();
+      continue;
+    }
+    if (is_cell) {   // MassMatrixOperator::local_apply of my cell, as k_mass
+      double pin[NP], pout[NP];
+#pragma unroll
+      for (int b = 0; b < NP; ++b) {
+        const double v = X[idx[b] & NODE_MASK];
+        pin[b] = ((idx[b] >> 29) & 1u) ? 0.0 : v;
+        pout[b] = 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+          const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
+          v = fma(w, pin[b], v);
+        }
+        if (TAB) v *= coef[q];
+        else v *= wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0) * scale * ie_c;
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+          const double w = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
+          pout[b] = fma(w, v, pout[b]);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < NP; ++b) slots[b * CS + t] = pout[b];
+    }
+    __syncthreads();
+    if (is_node) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < cnt) sum += slots[ent[k]];
+      const double Ax = con ? x : sum;
+      if (S.kind == SM_RESID) {
+        M.resid_out[t] = bv - Ax;
+      } else {
+        double v = fma(S.f2 * dv, bv - Ax, (1.0 + S.f1) * x);
+        if (S.use_xold) v = fma(-S.f1, xo, v);
+        xo = x;
+        x = v;
+        X[t] = x;
+      }
+    }
+    __syncthreads();
+  }
+  if (is_node) M.x_out[t] = x;
+}
+
 // ---- diagonals -------------------------------------------------------------------------
 // velocity: lane per (cell, local node); entry (a, c) = sum_q JxW eta (|grad phi|^2 + (d_c phi)^2
 //           [- 2/3 (d_c phi)^2 if compressible])
@@ -1015,6 +1136,26 @@ int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
   if (L.dim == 3) { if (gen) AGMG_MASS_LAUNCH(3, true); else AGMG_MASS_LAUNCH(3, false); }
   else { if (gen) AGMG_MASS_LAUNCH(2, true); else AGMG_MASS_LAUNCH(2, false); }
 #undef AGMG_MASS_LAUNCH
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SmootherProgram &prog,
+                         const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out) {
+  if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
+  if (!L.mass_fusable || prog.n < 1 || prog.n > SM_MAX_STEPS) { set_error("fused mass smoother: level or program does not fit"); return -1; }
+  const CellArgs a = make_args(L, cd, nullptr, nullptr, nullptr, nullptr);
+  const MassSmArgs m{L.pull_ptr_p, L.pull_list_p, L.cmask_p, dinv, b, x_in, x_out, resid_out, L.n_nodes_p};
+  const dim3 grid(1), block(MS_THREADS);
+  const bool perq = cd.nqv > 1, gen = L.geom == AGMG_GEOM_GENERAL;
+#define AGMG_MS_LAUNCH(D, G)                                                                     \
+  do {                                                                                           \
+    if (perq) hipLaunchKernelGGL((k_mass_smoother<D, true, G>), grid, block, 0, s, a, m, prog);  \
+    else hipLaunchKernelGGL((k_mass_smoother<D, false, G>), grid, block, 0, s, a, m, prog);      \
+  } while (0)
+  if (L.dim == 3) { if (gen) AGMG_MS_LAUNCH(3, true); else AGMG_MS_LAUNCH(3, false); }
+  else { if (gen) AGMG_MS_LAUNCH(2, true); else AGMG_MS_LAUNCH(2, false); }
+#undef AGMG_MS_LAUNCH
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }

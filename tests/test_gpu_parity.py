@@ -182,6 +182,22 @@ def test_device_coarse_level_matches_host_coarse(hip_lib):
     b.close()
 
 
+@pytest.mark.parametrize("name", ["nsinker_r2_perq", "nsinker_r2_harmonic", "box2d_r3_freeslip", "deformed3d_r3_perq", "deformed2d_r3_perq"])
+def test_fused_mass_smoother_matches_unfused(name, hip_lib, monkeypatch):
+    """small levels run whole Chebyshev sequences of the Schur mass smoother in one launch
+    (k_mass_smoother); same arithmetic as the launch-per-application path."""
+    p = PROBLEMS[name]().build()
+    monkeypatch.setenv("AGMG_NO_FUSED", "1")
+    a = capi.Solver(hip_lib, p, coarse_on_host=0)
+    monkeypatch.setenv("AGMG_NO_FUSED", "0")
+    b = capi.Solver(hip_lib, p, coarse_on_host=0)
+    src = rand_vec(a.size(capi.OP_MASS), 9, p.hier.finest, zero_constrained=False)
+    va, vb = a.vcycle(capi.OP_MASS, src), b.vcycle(capi.OP_MASS, src)
+    assert relerr(vb, va) < 1e-13
+    a.close()
+    b.close()
+
+
 def test_idr_and_expensive_paths(hip_lib, oracle_lib):
     p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, krylov="idr", tol=1e-7, n_cheap=1000, n_expensive=1000)
     g, o = make_pair(p, hip_lib, oracle_lib)
