@@ -81,7 +81,8 @@ class SolveReport(C.Structure):
 
 # every symbol include/agmg.h declares (suffix after the prefix)
 SYMBOLS = [
-    "default_options", "last_error", "create", "destroy", "set_communicator", "set_level", "set_coefficients",
+    "default_options", "last_error", "create", "destroy", "set_communicator",
+    "rccl_get_unique_id", "set_communicator_rccl", "set_level", "set_coefficients",
     "compute_diagonals", "vmult", "vmult_device", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
     "solve", "bench_vmult", "get_cell_data_memory_consumption",
@@ -126,6 +127,8 @@ class Library:
         self.create = fn("create", vp, [C.POINTER(Options)])
         self.destroy = fn("destroy", None, [vp])
         self.set_communicator = fn("set_communicator", C.c_int, [vp, vp])
+        self.rccl_get_unique_id = fn("rccl_get_unique_id", C.c_int, [C.POINTER(C.c_uint8)])
+        self.set_communicator_rccl = fn("set_communicator_rccl", C.c_int, [vp, C.POINTER(C.c_uint8)])
         self.set_level = fn("set_level", C.c_int, [vp, C.c_int, C.POINTER(LevelDesc)])
         self.set_coefficients = fn("set_coefficients", C.c_int, [vp, C.c_int, C.POINTER(CellData)])
         self.compute_diagonals = fn("compute_diagonals", C.c_int, [vp])
@@ -200,7 +203,11 @@ class Solver:
         self._keep = []
         self.transport = transport
         if transport is not None:
-            self._check(lib.set_communicator(self.ctx, C.addressof(transport.struct)))
+            if getattr(transport, "native_rccl", False):   # parallel.RcclTransport: in-library RCCL
+                ident = (C.c_uint8 * 128)(*transport.unique_id(lib))
+                self._check(lib.set_communicator_rccl(self.ctx, ident))
+            else:
+                self._check(lib.set_communicator(self.ctx, C.addressof(transport.struct)))
         for l, lev in enumerate(hier.levels):
             self._set_level(l, lev)
         self._check(lib.set_level(self.ctx, ACTIVE, None))

@@ -154,9 +154,11 @@ struct agmg_ctx {
   // ---- distributed contexts: transport callbacks + host staging
   agmg_comm comm{};
   bool comm_set = false;
+  void *rccl_state = nullptr;   // in-library RCCL transport (transport_rccl.cpp), or nullptr
   double *stage_h = nullptr;   // pinned; device_buffers == 0
   size_t stage_cap = 0;
-  bool dist() const { return opt.world_size > 1; }
+  // (a 1-rank context with a bound transport runs the distributed code paths too: tests)
+  bool dist() const { return opt.world_size > 1 || comm_set; }
   struct Msg { int peer; const double *send; int64_t n_send; double *recv; int64_t n_recv; };
   int exchange(const std::vector<Msg> &msgs);
   // owner -> ghost copies of `vec` (nc values per node, nc <= x.nc)
@@ -1434,6 +1436,20 @@ int agmg_set_communicator(agmg_ctx *c, const agmg_comm *comm) {
   return 0;
 }
 
+int agmg_rccl_get_unique_id(uint8_t id[128]) {
+  if (!id) { set_error("null argument"); return -1; }
+  return rccl_unique_id(id);
+}
+
+int agmg_set_communicator_rccl(agmg_ctx *c, const uint8_t id[128]) {
+  if (!c || !id) { set_error("null argument"); return -1; }
+  if (c->rccl_state) { set_error("RCCL transport already bound"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  CHECK(rccl_comm_create(id, c->opt.rank, c->opt.world_size, &c->comm, &c->rccl_state));
+  c->comm_set = true;
+  return 0;
+}
+
 void agmg_destroy(agmg_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->opt.device);
@@ -1448,6 +1464,7 @@ void agmg_destroy(agmg_ctx *c) {
   c->dfree(c->dot_partials); c->dfree(c->dot_out_d);
   if (c->dot_out_h) (void)hipHostFree(c->dot_out_h);
   if (c->stage_h) (void)hipHostFree(c->stage_h);
+  rccl_comm_destroy(c->rccl_state);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -189,6 +189,11 @@ int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLe
 int launch_restrict_cells(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
                           const double *src_fine, double *slots);
 
+// ---- in-library RCCL transport (transport_rccl.cpp) ----
+int rccl_unique_id(uint8_t id[128]);
+int rccl_comm_create(const uint8_t id[128], int rank, int size, agmg_comm *out, void **state);
+void rccl_comm_destroy(void *state);
+
 // ---- vector kernels (kernels_vec.hip) ----
 int vec_set(hipStream_t s, double *x, double v, size_t n);
 int vec_copy(hipStream_t s, double *dst, const double *src, size_t n);

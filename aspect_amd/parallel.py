@@ -197,3 +197,29 @@ class Transport:
             import sys
             print(f"[aspect_amd transport] all-reduce failed on rank {self.r.rank}: {e!r}", file=sys.stderr, flush=True)
             return -1
+
+
+class RcclTransport:
+    """Marker transport for capi.Solver: the library's own RCCL transport
+    (agmg_set_communicator_rccl).  torch.distributed only carries the 128-byte unique id from rank 0
+    to the other ranks; every exchange and all-reduce then runs inside the library on its stream."""
+    native_rccl = True
+
+    def __init__(self, ranks: Ranks):
+        self.r = ranks
+        self.struct = CommStruct(ranks.rank, ranks.world, 1, None, EXCHANGE_FN(), ALLREDUCE_FN())
+        self.n_exchange = self.n_allreduce = -1   # not observable from the host
+
+    def unique_id(self, lib):
+        torch, dist = self.r.torch, self.r.dist
+        buf = (C.c_uint8 * 128)()
+        if self.r.rank == 0:
+            rc = lib.rccl_get_unique_id(buf)
+            if rc:
+                raise RuntimeError(lib.last_error().decode())
+        t = torch.tensor(list(buf), dtype=torch.uint8)
+        if self.r.world > 1:
+            if self.r.backend == "nccl":
+                t = t.to(self.r.device)
+            dist.broadcast(t, src=0)
+        return [int(v) for v in t.cpu().tolist()]

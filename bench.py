@@ -94,9 +94,12 @@ def main():
         src_h[:fin.n_dofs_v][fin.constrained_dofs_v()] = 0.0
         return prob, solver, fin, src_h, fin.n_dofs_v, fin.n_dofs_p
 
+    transport_name = ""
+
     def distributed_setup():
+        nonlocal transport_name
         from aspect_amd import partition
-        from aspect_amd.parallel import Transport
+        from aspect_amd.parallel import RcclTransport, Transport
         reps = {2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}.get(world)
         if reps is None:
             raise ValueError(f"no subdomain layout for {world} ranks")
@@ -104,13 +107,43 @@ def main():
         g.reps, g.extents = reps, [float(r) for r in reps]
         g.build()
         loc = partition.LocalProblem(g, rank, world)
-        tr = Transport(ranks)
-        solver = capi.Solver(lib, loc, transport=tr, device=local_rank)
         gf = g.hier.finest
         src_g = np.sin(0.37 * np.arange(gf.n_dofs_v + gf.n_dofs_p))
         src_g[:gf.n_dofs_v][gf.constrained_dofs_v()] = 0.0
+        src_l = loc.to_local(src_g)
+        own = loc.owned_block()[0]
+
+        def one_vmult(solver):
+            s_ = torch.from_numpy(src_l).to(dev)
+            d_ = torch.zeros_like(s_)
+            if lib.vmult_device(solver.ctx, capi.OP_STOKES, capi.ACTIVE, d_.data_ptr(), s_.data_ptr()):
+                raise RuntimeError(lib.last_error().decode())
+            torch.cuda.synchronize()
+            return d_.cpu().numpy()[own]
+
+        # reference transport: torch.distributed callbacks (RCCL point-to-point through PyTorch)
+        solver = capi.Solver(lib, loc, transport=Transport(ranks), device=local_rank)
+        ref = one_vmult(solver)
+        transport_name = "torch.distributed callbacks"
+        want = os.environ.get("AGMG_TRANSPORT", "rccl" if backend == "nccl" else "torch")
+        if want == "rccl":
+            # the library's own RCCL transport (no host code per exchange); kept only if every rank
+            # reproduces the reference transport's result
+            bad = 0.0
+            try:
+                native = capi.Solver(lib, loc, transport=RcclTransport(ranks), device=local_rank)
+                got = one_vmult(native)
+                if not np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max()):
+                    bad = 1.0
+            except Exception as e:  # noqa: BLE001
+                bad = 1.0
+                print(f"[bench] rank {rank}: in-library RCCL transport unavailable ({e!r})", file=sys.stderr)
+            if max_over_ranks(bad) == 0:
+                solver.close()
+                solver = native
+                transport_name = "in-library RCCL (grouped ncclSend/ncclRecv + ncclAllReduce on the library stream)"
         # whole-job DoFs / N = DoFs per GPU (owned)
-        return loc, solver, loc.hier.finest, loc.to_local(src_g), gf.n_dofs_v / world, gf.n_dofs_p / world
+        return loc, solver, loc.hier.finest, src_l, gf.n_dofs_v / world, gf.n_dofs_p / world
 
     parallelism = "1 rank"
     if world > 1:
@@ -131,7 +164,7 @@ def main():
             parallelism = f"{world} independent subdomain replicas (distributed set-up failed on this node)"
         else:
             parallelism = (f"{world} subdomains (one unit cube per GPU), ghost update + compress per vmult and "
-                           f"all-reduce per dot product over RCCL (torch.distributed)")
+                           f"all-reduce per dot product; transport: {transport_name}")
     else:
         prob, solver, fin, src_h, nu, npd = serial_setup()
     n = nu + npd

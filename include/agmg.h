@@ -75,9 +75,9 @@ typedef struct agmg_options {
   int32_t coarse_eig_cg_n_iterations; /* 100 */
   int32_t schur_smoother_steps;  /* mg_smoother_Schur(4) */
   /* multi-GPU: world size/rank of this context (one rank <-> one GPU <-> one
-   * subdomain).  world_size > 1 needs agmg_set_communicator before any table is
-   * set.  nccl_id is reserved (an in-library RCCL transport would take its
-   * unique id here); it is ignored today. */
+   * subdomain).  world_size > 1 needs a transport before any table is set:
+   * agmg_set_communicator_rccl (in-library RCCL) or agmg_set_communicator (host
+   * callbacks).  nccl_id is unused (the id goes to agmg_set_communicator_rccl). */
   int32_t world_size;
   int32_t rank;
   uint8_t nccl_id[128];
@@ -199,6 +199,16 @@ void      agmg_destroy(agmg_ctx *ctx);
  * internally (the library writes them, also in `src` arguments on the
  * device); only owned entries of outputs are meaningful. */
 int agmg_set_communicator(agmg_ctx *ctx, const agmg_comm *comm);
+
+/* In-library transport: RCCL (xGMI inside a node) called directly on the
+ * context's stream: one grouped ncclSend/ncclRecv launch per ghost exchange, one
+ * ncclAllReduce per fused dot product, no host synchronisation.  Rank 0 obtains
+ * an id with agmg_rccl_get_unique_id and hands the 128 bytes to every rank by any
+ * means (the reference would MPI_Bcast them); agmg_set_communicator_rccl is then
+ * collective over the ranks of the context (ncclCommInitRank), with the
+ * context's device current.  Takes the place of agmg_set_communicator. */
+int agmg_rccl_get_unique_id(uint8_t id[128]);
+int agmg_set_communicator_rccl(agmg_ctx *ctx, const uint8_t id[128]);
 
 /* setup_dofs(): upload the tables of one level (local_smoothing.cc:1548-1878).
  * level in [0, n_levels) or AGMG_ACTIVE. desc == NULL for AGMG_ACTIVE aliases

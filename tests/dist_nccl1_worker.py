@@ -34,6 +34,22 @@ def main():
     # exchange with no messages is a no-op that must not fail
     rc = tr._exchange(None, 0, None, None, None, None, None, side.cuda_stream)
     ok = ok and rc == 0
+    # the library's own RCCL transport on a 1-rank communicator: id hand-over, ncclCommInitRank,
+    # ncclAllReduce on the library stream inside every dot product of a whole solve
+    import numpy as np
+    from aspect_amd import capi, cases, partition
+    g = cases.nsinker_box(2, n_sinkers=4, ratio=1e4).build()
+    loc = partition.LocalProblem(g, 0, 1)
+    plain = capi.Solver(capi.load(), g)
+    native = capi.Solver(capi.load(), loc, transport=parallel.RcclTransport(ranks))
+    xa, ra, _ = plain.solve()
+    xb, rb, _ = native.solve()
+    same = ra.n_cheap_iterations == rb.n_cheap_iterations and \
+        np.linalg.norm(xa - xb) <= 1e-6 * np.linalg.norm(xa)
+    print(f"[nccl1] native RCCL transport: iterations {rb.n_cheap_iterations} vs {ra.n_cheap_iterations}", flush=True)
+    ok = ok and same
+    plain.close()
+    native.close()
     print(f"[nccl1] {'ok' if ok else 'FAIL'}", flush=True)
     ranks.dist.destroy_process_group()
     sys.exit(0 if ok else 1)
