@@ -682,10 +682,8 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
   eu.dst = dst; eu.x = src;
   ep.dst = dst + nu; ep.x = src + nu;
   if (eu_in.b) ep.b = eu_in.b + nu;
-  if (!dist()) {
-    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks));
-    return launch_pull_p(stream, lv, slots_p, lv.dim, ep);
-  }
+  if (!dist())
+    return launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_ALL, &ep);
   std::vector<Msg> m;
   CHECK(add_update(m, lv.xv, const_cast<double *>(src), lv.xv.nc));
   CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
@@ -1727,9 +1725,9 @@ int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const doub
         if (l != c->nl() - 1 || &cd != &c->active_coeff()) { set_error("distributed Stokes vmult: active mesh only"); return -2; }
         return c->stokes_vmult(dst, src);
       }
-      CHECK(launch_op(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p, e, c->use_blocks));
-      e.dst = dst + nu; e.x = src + nu;
-      return launch_pull_p(c->stream, lv, c->slots_p, lv.dim, e);
+      EpiArgs ep = e;
+      ep.dst = dst + nu; ep.x = src + nu;
+      return launch_op(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p, e, c->use_blocks, PH_ALL, &ep);
     }
     default: {  // B^T: both blocks of dst are written (vmult zeroes dst first)
       if (c->dist()) {

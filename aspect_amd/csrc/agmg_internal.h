@@ -160,10 +160,11 @@ enum Phase { PH_ALL = 0, PH_GHOST = 1, PH_OWNED = 2 };
 int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e, int phase = PH_ALL);
 // Whole velocity-row application: cell phase + reduction + epilogue `eu` on the velocity rows.
 // Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.
-// Stokes pressure rows are left in slots_p for launch_pull_p(..., dim, ...).
+// Stokes pressure rows are left in slots_p for launch_pull_p(..., dim, ...), or finished here with
+// epilogue *ep (one rank: the velocity fix-up and the pressure pull share one launch).
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,
-              int phase = PH_ALL);
+              int phase = PH_ALL, const EpiArgs *ep = nullptr);
 // n_parts: partial values per (cell, i) slot (dim for the Stokes pressure rows, 1 for mass)
 int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int n_parts, const EpiArgs &e,
                   int phase = PH_ALL);

@@ -738,8 +738,8 @@ __device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, cons
 
 // NC: components per node (one thread each); NPARTS: partial values per slot summed by the thread
 template <int NC, int NPARTS>
-__global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
-  const long tl = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pull_body(const PullArgs &P, const unsigned block) {
+  const long tl = (long)block * 256 + threadIdx.x;
   if (tl >= (long)P.n_range * NC) return;
   const int nl = (int)(tl / NC), c = (int)(tl - (long)nl * NC);
   const int node = P.node0 + nl;
@@ -761,6 +761,8 @@ __global__ void __launch_bounds__(256) k_pull(const PullArgs P) {
   double out;
   if (epi_value(P.e, t, sum, con, out)) P.e.dst[t] = out;
 }
+template <int NC, int NPARTS>
+__global__ void __launch_bounds__(256) k_pull(const PullArgs P) { pull_body<NC, NPARTS>(P, blockIdx.x); }
 
 // ---- block scatter: one workgroup = WAVES_PER_BLOCK batches of cells ("block").  Every lane
 // parks its 3^DIM contributions in an LDS slot tile; after one barrier the workgroup sums, per
@@ -1003,8 +1005,8 @@ struct FixArgs {
   EpiArgs e;
 };
 template <int NC>
-__global__ void __launch_bounds__(256) k_fix(const FixArgs F) {
-  const int il = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void fix_body(const FixArgs &F, const unsigned block) {
+  const int il = (int)block * 256 + threadIdx.x;
   if (il >= F.n_range) return;
   const int i = F.i0 + il;
   const uint32_t s = F.sh_ptr[i], en = F.sh_ptr[i + 1];
@@ -1031,6 +1033,15 @@ __global__ void __launch_bounds__(256) k_fix(const FixArgs F) {
     double out;
     if (epi_value(F.e, g0 + c, sum[c], con, out)) F.e.dst[g0 + c] = out;
   }
+}
+template <int NC>
+__global__ void __launch_bounds__(256) k_fix(const FixArgs F) { fix_body<NC>(F, blockIdx.x); }
+// Stokes: the fix-up of the velocity rows and the pull of the pressure rows are independent of
+// each other (both only wait for the cell kernel): one launch, the grid split between them
+template <int DIM>
+__global__ void __launch_bounds__(256) k_fix_pull(const FixArgs F, const PullArgs P, const unsigned n_fix_blocks) {
+  if (blockIdx.x < n_fix_blocks) fix_body<DIM>(F, blockIdx.x);
+  else pull_body<1, DIM>(P, blockIdx.x - n_fix_blocks);
 }
 
 CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
@@ -1219,13 +1230,18 @@ int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int 
 }
 
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
-              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks, int phase) {
+              const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks, int phase,
+              const EpiArgs *ep) {
+  // ep (Stokes, PH_ALL only): also finish the pressure rows (pull of slots_p with epilogue *ep)
+  if (ep && (which != AGMG_OP_STOKES || phase != PH_ALL)) { set_error("launch_op: pressure epilogue misuse"); return -1; }
   if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB)) {
     if (phase != PH_OWNED) {
       const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
       if (rc) return rc;
     }
-    return launch_pull_v(s, L, slots_u, eu, phase);
+    const int rc = launch_pull_v(s, L, slots_u, eu, phase);
+    if (rc || !ep) return rc;
+    return launch_pull_p(s, L, slots_p, L.dim, *ep, PH_ALL);
   }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
@@ -1280,7 +1296,18 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
   }
 #endif
   if (phase == PH_GHOST) return fix(bt.n_shared_owned, bt.n_shared - bt.n_shared_owned, true);
-  return fix(0, bt.n_shared, false);
+  if (!ep) return fix(0, bt.n_shared, false);
+  if (bt.n_shared <= 0) return launch_pull_p(s, L, slots_p, L.dim, *ep, PH_ALL);
+  {  // one launch for the velocity fix-up and the pressure pull
+    FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, 0, bt.n_shared, 0xFFFFFFFFu, nullptr, nullptr, L.n_owned_v, eu};
+    PullArgs p{L.pull_ptr_p, L.pull_list_p, slots_p, L.cmask_p, 0, L.n_nodes_p, 0xFFFFFFFFu, nullptr, nullptr, *ep};
+    const unsigned nf = (unsigned)((bt.n_shared + 255) / 256), np = (unsigned)((L.n_nodes_p + 255) / 256);
+    const dim3 grid(nf + np), block(256);
+    if (L.dim == 3) hipLaunchKernelGGL((k_fix_pull<3>), grid, block, 0, s, f, p, nf);
+    else hipLaunchKernelGGL((k_fix_pull<2>), grid, block, 0, s, f, p, nf);
+    AGMG_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
 }
 
 }  // namespace agmg
