@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../aspect_amd/csrc"
 for n in "$@"; do
   d=../../build/abl$n; mkdir -p $d
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGMG_ABLATE=$n -c kernels_ops.hip -o $d/kernels_ops.o
-  hipcc --offload-arch=gfx950 -shared -o $d/libaspect_amd.so agmg.o $d/kernels_ops.o kernels_transfer.o kernels_vec.o
+  hipcc --offload-arch=gfx950 -shared -o $d/libaspect_amd.so agmg.o $d/kernels_ops.o kernels_transfer.o kernels_vec.o transport_rccl.o -ldl
 done
