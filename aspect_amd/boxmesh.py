@@ -79,9 +79,13 @@ BC_NONE, BC_ZERO, BC_TANGENTIAL = 0, 1, 2
 class Level:
     """Flat tables of one mesh level (what ``agmg_level_desc`` carries)."""
 
-    def __init__(self, dim, extents, reps, l, bc, deform=None):
+    def __init__(self, dim, extents, reps, l, bc, deform=None, periodic=None):
         self.dim = dim
         self.deform = deform
+        # periodic directions (geometry_model/box.cc "X periodic"): the nodes of the upper face are
+        # the nodes of the lower face, i.e. periodicity is plain cell -> node connectivity here
+        # (deal.II keeps both DoFs and constrains one to the other: the same reduced system)
+        self.periodic = [False] * dim if periodic is None else [bool(b) for b in periodic]
         self.level = l
         self.extents = np.asarray(extents, dtype=np.float64)
         self.reps = np.asarray(reps, dtype=np.int64)
@@ -100,9 +104,10 @@ class Level:
         self.cell_ijk = np.stack([cc[d] * (1 << l) + local[d] for d in range(dim)], axis=1)
 
         # velocity (Q2) nodes
-        self.nvd = 2 * self.ncd + 1
+        wrap = np.array([1 if b else 0 for b in self.periodic], dtype=np.int64)
+        self.nvd = 2 * self.ncd + 1 - wrap
         self.n_nodes_v = int(np.prod(self.nvd))
-        self.npd = self.ncd + 1
+        self.npd = self.ncd + 1 - wrap
         self.n_nodes_p = int(np.prod(self.npd))
         self.cell_nodes_v = self._cell_nodes(3, 2, self.nvd)
         self.cell_nodes_p = self._cell_nodes(2, 1, self.npd)
@@ -138,7 +143,7 @@ class Level:
             strides[d] = strides[d - 1] * nd[d - 1]
         out = np.zeros((self.n_cells, n1 ** dim), dtype=np.int64)
         for d in range(dim):
-            out += (stride * self.cell_ijk[:, d:d + 1] + loc[d][None, :]) * strides[d]
+            out += ((stride * self.cell_ijk[:, d:d + 1] + loc[d][None, :]) % nd[d]) * strides[d]
         return out.astype(np.uint32)
 
     def node_coords_v(self):
@@ -159,6 +164,8 @@ class Level:
         mask = np.zeros(self.n_nodes_v, dtype=np.uint8)
         allbits = (1 << dim) - 1
         for d in range(dim):
+            if self.periodic[d]:
+                continue
             for side in range(2):
                 code = bc[2 * d + side]
                 on = idx[d] == (0 if side == 0 else self.nvd[d] - 1)
@@ -180,6 +187,10 @@ class Level:
             out[:, :, d] = (self.cell_ijk[:, d:d + 1] + GAUSS3_X[q[d]][None, :]) * self.h[d]
         return out
 
+    def nodal_to_qpoints(self, nodal):
+        """Q2 field given at the velocity nodes -> values at the Gauss points, [n_cells][nq]."""
+        return nodal[self.cell_nodes_v.astype(np.int64)] @ tensor_shape([N2] * self.dim).T
+
     def cell_centers(self):
         return (self.cell_ijk + 0.5) * self.h[None, :]
 
@@ -200,14 +211,15 @@ class Level:
 class BoxHierarchy:
     """Levels 0..refinement of a box; level ``refinement`` is also the active mesh."""
 
-    def __init__(self, dim, refinement, extents=None, reps=None, bc=None, only_finest=False, deform=None):
+    def __init__(self, dim, refinement, extents=None, reps=None, bc=None, only_finest=False, deform=None,
+                 periodic=None):
         self.dim = dim
         extents = [1.0] * dim if extents is None else extents
         reps = [1] * dim if reps is None else reps
         bc = [BC_TANGENTIAL] * (2 * dim) if bc is None else bc
         self.bc = list(bc)
         first = refinement if only_finest else 0
-        self.levels = [Level(dim, extents, reps, l, bc, deform) for l in range(first, refinement + 1)]
+        self.levels = [Level(dim, extents, reps, l, bc, deform, periodic) for l in range(first, refinement + 1)]
 
     @property
     def finest(self):
@@ -316,11 +328,15 @@ def viscosity_tables(hier, eta_func, averaging):
 # ---------------------------------------------------------------------------
 # Right-hand side  f_u = int rho g . phi_u  (assemblers/stokes.cc:433-442)
 # ---------------------------------------------------------------------------
-def assemble_rhs_u(level, force_func):
-    """force_func(x[n,dim]) -> rho*g [n,dim]; constrained rows are zeroed."""
+def assemble_rhs_u(level, force_func, force_q=None):
+    """force_func(x[n,dim]) -> rho*g [n,dim], or force_q(level) -> rho*g at the q-points
+    [n_cells,nq,dim]; constrained rows are zeroed."""
     dim = level.dim
-    xq = level.qpoint_coords()
-    f = force_func(xq.reshape(-1, dim)).reshape(level.n_cells, -1, dim)
+    if force_q is not None:
+        f = force_q(level)
+    else:
+        xq = level.qpoint_coords()
+        f = force_func(xq.reshape(-1, dim)).reshape(level.n_cells, -1, dim)
     Nq = tensor_shape([N2] * dim)                      # [q][i]
     if level.general:
         loc = np.einsum("qi,cq,cqd->cid", Nq, level.jxw, f)

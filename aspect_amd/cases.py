@@ -57,15 +57,17 @@ class StokesProblem:
     idr_s: int = 2
     initial_pressure: callable = None   # x -> p0 (unscaled), static pressure guess
     deform: callable = None             # x -> x' smooth map of the box (general / MappingQ geometry)
+    periodic: list = None               # periodic directions of the box
+    force_q: callable = None            # level -> rho*g at the q-points [n_cells, nq, dim] (FE-field densities)
     hier: bm.BoxHierarchy = field(default=None, repr=False)
 
     def build(self):
         self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    deform=self.deform)
+                                    deform=self.deform, periodic=self.periodic)
         self.eta_active, self.eta_levels, self.eta_min, self.eta_max = \
             bm.viscosity_tables(self.hier, self.eta, self.averaging)
         fin = self.hier.finest
-        self.rhs_u = bm.assemble_rhs_u(fin, self.force)
+        self.rhs_u = bm.assemble_rhs_u(fin, self.force, self.force_q)
         self.rhs_p = np.zeros(fin.n_dofs_p)
         if self.initial_pressure is not None:
             self.p0 = self.initial_pressure(fin.node_coords_p()) / self.pressure_scaling
@@ -76,7 +78,7 @@ class StokesProblem:
     def build_single_level(self):
         """Only the active mesh (operator benchmarks on big levels: no hierarchy, no RHS)."""
         self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    only_finest=True, deform=self.deform)
+                                    only_finest=True, deform=self.deform, periodic=self.periodic)
         fin = self.hier.finest
         nq = 3 ** self.dim
         if self.averaging == bm.AVG_HARMONIC:
@@ -223,3 +225,38 @@ def deformed_sinker_box(dim, refinement, amplitude=0.06, ratio=1e3, averaging=bm
         name=f"deformed_sinker_{dim}d_r{refinement}", dim=dim, refinement=refinement,
         bc=[bm.BC_ZERO] * (2 * dim), eta=eta, force=force, averaging=averaging,
         pressure_scaling=1.0, deform=deform, **args)
+
+
+def periodic_box_2d(refinement=5, no_slip_walls=False):
+    """tests/periodic_box_gmg.prm, first Stokes solve: 2-D box 1e6 x 5e5, periodic in x, free slip on
+    top and bottom, isoviscous 1e20 (harmonic averaging), two hot blobs (T = 800) in a cold box with
+    the bottom boundary temperature 1000 imposed on the bottom nodes; density 3300 (1 - 4e-5 T),
+    g = 10; tolerance 1e-8, 100 cheap steps.
+    With free slip the A block has the x-translation in its kernel (the deck removes it afterwards,
+    "Remove nullspace = net x translation"), so the 100-step CG eigenvalue estimate of the 12-DoF
+    coarse level runs on rounding noise and everything downstream of it (smoother ranges, iteration
+    counts) is rounding-dependent; no_slip_walls = True gives the well-posed variant."""
+    X, Y = 1.0e6, 5.0e5
+
+    def temperature_nodal(x):
+        t = np.where((np.sqrt((x[:, 0] - 1e5) ** 2 + (x[:, 1] - 4.0e5) ** 2) < 5.0e4) |
+                     (np.sqrt((x[:, 0] - 3e5) ** 2 + (x[:, 1] - 2e5) ** 2) < 1.0e5), 800.0, 0.0)
+        t[x[:, 1] <= 0.0] = 1000.0           # fixed temperature boundary: bottom 1000, top 0
+        t[x[:, 1] >= Y] = 0.0
+        return t
+
+    def force_q(level):
+        tq = level.nodal_to_qpoints(temperature_nodal(level.node_coords_v()))   # Q2 temperature field
+        f = np.zeros(tq.shape + (2,))
+        f[:, :, 1] = -10.0 * 3300.0 * (1.0 - 4e-5 * tq)
+        return f
+
+    def p_static(x):
+        return 3300.0 * 10.0 * (Y - x[:, 1])
+
+    return StokesProblem(
+        name=f"periodic_box_2d_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_NONE, bm.BC_NONE] + [bm.BC_ZERO if no_slip_walls else bm.BC_TANGENTIAL] * 2,
+        eta=lambda x: np.full(x.shape[0], 1e20), force=None, force_q=force_q,
+        averaging=bm.AVG_HARMONIC, pressure_scaling=1e20 / (0.01 * X), extents=[X, Y],
+        periodic=[True, False], tol=1e-8, n_cheap=100, n_expensive=1000, initial_pressure=p_static)

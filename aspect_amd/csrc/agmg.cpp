@@ -590,8 +590,10 @@ int agmg_ctx::ensure_transfers() {
       const int nn = vel ? F.n_nodes_v : F.n_nodes_p;
       std::vector<uint32_t> par(nn, 0xFFFFFFFFu);
       std::vector<uint8_t> pos(nn, 0);
-      std::vector<int> stamp(nn, -1);
+      // multiplicity = occurrences (parent, patch position) of a fine node (on a periodic mesh one
+      // cell wide both faces of a patch are the same fine nodes and count twice)
       std::vector<double> mult(nn, 0.0);
+      std::vector<int> seen(ipow(nf, dim), -1);
       for (int p = 0; p < C.n_cells; ++p)
         for (int ch = 0; ch < nch; ++ch) {
           const uint32_t f = children[(size_t)ch * C.cstride + p];
@@ -604,7 +606,7 @@ int agmg_ctx::ensure_transfers() {
               stride *= nf;
             }
             const uint32_t fn = cn[(size_t)f * nloc + i];
-            if (stamp[fn] != p) { stamp[fn] = p; mult[fn] += 1.0; }
+            if (seen[pidx] != p) { seen[pidx] = p; mult[fn] += 1.0; }
             if (par[fn] == 0xFFFFFFFFu) { par[fn] = p; pos[fn] = (uint8_t)pidx; }
           }
         }

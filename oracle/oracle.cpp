@@ -673,8 +673,8 @@ void transfer(const Ctx &C, int which, int fine_level, bool prolong, Vec &dst, c
   const double *P1d = vel ? &T.P2[0][0] : &T.P1[0][0];
   const std::vector<uint32_t> &cnF = vel ? F.cnv : F.cnp, &cnC = vel ? Cs.cnv : Cs.cnp;
   const int nnF = vel ? F.n_nodes_v : F.n_nodes_p;
-  // multiplicity of fine nodes over parent patches
-  std::vector<int> stamp(nnF, -1);
+  // multiplicity of fine nodes over parent patches: occurrences (parent, patch position); on a
+  // periodic mesh one cell wide the two faces of a patch are the same fine nodes
   std::vector<double> weight(nnF, 0.0);
   const int nchild = 1 << DIM;
   std::vector<std::vector<int>> children(Cs.n_cells, std::vector<int>(nchild, -1));
@@ -697,7 +697,7 @@ void transfer(const Ctx &C, int which, int fine_level, bool prolong, Vec &dst, c
   std::vector<uint32_t> pn;
   for (int p = 0; p < Cs.n_cells; ++p) {
     patch_nodes(p, pn);
-    for (int i = 0; i < npatch; ++i) if (stamp[pn[i]] != p) { stamp[pn[i]] = p; weight[pn[i]] += 1.0; }
+    for (int i = 0; i < npatch; ++i) weight[pn[i]] += 1.0;
   }
   for (auto &w : weight) w = 1.0 / w;
   auto coarse_constrained = [&](int node, int c) { return vel ? Cs.constrained_v(node, c) : Cs.constrained_p(node); };

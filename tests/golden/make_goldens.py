@@ -11,7 +11,7 @@ import sys
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", "nsinker_gmg_idr",
          "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
-         "particle_interpolator_bilinear_3d"]
+         "particle_interpolator_bilinear_3d", "periodic_box_gmg"]
 
 
 def parse(path):

@@ -41,6 +41,8 @@ PROBLEMS = {
     "deformed3d_r3_perq": lambda: cases.deformed_sinker_box(3, 3),
     "deformed3d_r2_harmonic": lambda: cases.deformed_sinker_box(3, 2, averaging=bm.AVG_HARMONIC),
     "deformed2d_r3_perq": lambda: cases.deformed_sinker_box(2, 3),
+    # periodic in x: opposite faces share their nodes (level 0 is one cell wide: a cell meets itself)
+    "periodic2d_r4": lambda: cases.periodic_box_2d(4, no_slip_walls=True),
 }
 
 

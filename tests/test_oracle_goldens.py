@@ -140,3 +140,49 @@ def test_operator_properties():
     st = s.vmult(capi.OP_STOKES, np.concatenate([x, np.zeros(fin.n_dofs_p)]))[nu:]
     assert abs(x @ bt - q @ st) <= 1e-12 * abs(x @ bt)
     s.close()
+
+
+def test_periodic_box_tables_transfer_and_solve():
+    """tests/periodic_box_gmg.prm (first solve) restated with periodicity as connectivity: opposite
+    faces share their nodes.  Pinned by the reference golden: 1024 cells on 6 levels and the DoF
+    counts once deal.II's duplicated periodic DoFs (one node column / pressure column) are merged.
+    NOT reproduced, and said so in DESIGN.md: the reference's iteration count on this case (53+0).
+    With free slip the A block has the x-translation in its kernel, so the 100-step CG eigenvalue
+    estimate of the 12-DoF coarse level runs on rounding noise and the count is rounding-dependent
+    (11 here): the periodic solve is unpinned by the reference; the solve is checked on the
+    well-posed no-slip variant.
+    Checked instead: sum-factorised = dense bilinear form, restriction = transpose of prolongation
+    and prolongation reproduces constants on every level pair, including the one whose coarse level
+    is a single cell that meets itself (multiplicity counted per patch position)."""
+    g = G["periodic_box_gmg"]
+    p = cases.periodic_box_2d(5).build()
+    fin = p.hier.finest
+    m = g["meshes"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] - 2 * 65 and fin.n_dofs_p == m["dofs_p"] - 33
+    assert abs(p.eta_min / g["solves"][0]["eta_min"] - 1) < 1e-12 and abs(p.eta_max / g["solves"][0]["eta_max"] - 1) < 1e-12
+    s = pyoracle.solver(p)
+    rng = np.random.Generator(np.random.PCG64(11))
+    for which in (capi.OP_A, capi.OP_STOKES, capi.OP_MASS):
+        for level in (capi.ACTIVE, 0, 1):
+            src = rng.uniform(-1, 1, s.size(which, level))
+            a, b = s.vmult(which, src, level), s.vmult(which, src, level, dense=True)
+            assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(b)
+    for level in range(1, p.hier.n_levels):
+        for which in (capi.OP_A, capi.OP_MASS):
+            nf, nc = s.size(which, level), s.size(which, level - 1)
+            u, v = rng.uniform(-1, 1, nc), rng.uniform(-1, 1, nf)
+            if which == capi.OP_A:
+                u[p.hier.levels[level - 1].constrained_dofs_v()] = 0.0
+                v[p.hier.levels[level].constrained_dofs_v()] = 0.0
+            pu = s.prolongate_add(which, level, np.zeros(nf), u)
+            rv = s.restrict_add(which, level, np.zeros(nc), v)
+            assert abs(pu @ v - u @ rv) <= 1e-12 * abs(pu @ v)
+        ones = s.prolongate_add(capi.OP_MASS, level, np.zeros(s.size(capi.OP_MASS, level)),
+                                np.ones(s.size(capi.OP_MASS, level - 1)))
+        assert np.abs(ones - 1.0).max() < 1e-14
+    s.close()
+    s = pyoracle.solver(cases.periodic_box_2d(5, no_slip_walls=True).build())
+    x, rep, rc = s.solve()
+    assert rc == 0 and rep.n_cheap_iterations <= 20 and rep.final_linear_residual <= rep.solver_tolerance
+    s.close()
