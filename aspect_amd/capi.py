@@ -271,10 +271,19 @@ class Solver:
         self._check(self.lib.set_level(self.ctx, l, C.byref(d)))
         self._keep.append(keep)
 
-    def _set_coeff(self, l, table, is_compressible=0):
+    def _set_coeff(self, l, table, is_compressible=0, newton=None, symmetrize=0):
+        """newton = (strain_rate [cells][nq][ns], newton_factor_wrt_strain_rate [cells][nq][ns],
+        newton_factor_wrt_pressure [cells][nq]): enables the Newton-derivative terms (active level)."""
         t = np.ascontiguousarray(table, dtype=np.float64)
         cd = CellData()
         cd.is_compressible = is_compressible
+        if newton is not None:
+            nt = [np.ascontiguousarray(a, dtype=np.float64) for a in newton]
+            cd.enable_newton_derivatives = 1
+            cd.symmetrize_newton_system = int(symmetrize)
+            cd.strain_rate_table = _ptr(nt[0], C.c_double)
+            cd.newton_factor_wrt_strain_rate = _ptr(nt[1], C.c_double)
+            cd.newton_factor_wrt_pressure = _ptr(nt[2], C.c_double)
         cd.pressure_scaling = self.problem.pressure_scaling
         cd.n_q_viscosity = t.shape[1]
         cd.viscosity = _ptr(t, C.c_double)

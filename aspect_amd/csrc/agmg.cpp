@@ -1455,7 +1455,7 @@ void agmg_destroy(agmg_ctx *c) {
   (void)hipSetDevice(c->opt.device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &l : c->L) c->free_level(l);
-  c->dfree(c->active.etaT);
+  c->dfree(c->active.etaT); c->dfree(c->active.nw_strain); c->dfree(c->active.nw_dEde); c->dfree(c->active.nw_dEdp);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
   for (int w = 0; w < 2; ++w)
     for (auto *v : {&c->mg_def[w], &c->mg_sol[w], &c->mg_tmp[w], &c->mg_t[w]})
@@ -1634,9 +1634,17 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
 int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   if (!c || !d) { set_error("null argument"); return -1; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
-  if (d->enable_newton_derivatives || d->enable_prescribed_dilation) {
-    set_error("Newton-derivative / prescribed-dilation terms are not built (SURVEY.md 8f3)");
+  if (d->enable_prescribed_dilation) {
+    set_error("prescribed-dilation terms are not built (SURVEY.md 8f3)");
     return -2;
+  }
+  if (d->enable_newton_derivatives) {
+    // the tables exist on the active level only (local_smoothing.cc:447-663); the level operators
+    // of the preconditioner stay Picard operators
+    if (level != AGMG_ACTIVE) { set_error("Newton-derivative tables belong to the active level (AGMG_ACTIVE)"); return -1; }
+    if (!d->strain_rate_table || !d->newton_factor_wrt_strain_rate || !d->newton_factor_wrt_pressure) {
+      set_error("Newton-derivative tables missing"); return -1;
+    }
   }
   if (level != AGMG_ACTIVE && (level < 0 || level >= c->nl())) { set_error("bad level"); return -1; }
   DeviceLevel &lv = level == AGMG_ACTIVE ? c->fin() : c->L[level];
@@ -1659,6 +1667,24 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   cd.lambda = d->pressure_scaling;
   cd.is_compressible = d->is_compressible;
   cd.bytes = T.size() * 8;
+  c->dfree(cd.nw_strain); c->dfree(cd.nw_dEde); c->dfree(cd.nw_dEdp);
+  cd.newton = false;
+  if (d->enable_newton_derivatives) {
+    const int dim = c->opt.dim, NS = dim * (dim + 1) / 2;
+    std::vector<double> E((size_t)NQ * NS * cs, 0.0), D((size_t)NQ * NS * cs, 0.0), P((size_t)NQ * cs, 0.0);
+    for (int cell = 0; cell < lv.n_cells; ++cell)
+      for (int q = 0; q < NQ; ++q) {
+        for (int k = 0; k < NS; ++k) {
+          E[((size_t)q * NS + k) * cs + cell] = d->strain_rate_table[((size_t)cell * NQ + q) * NS + k];
+          D[((size_t)q * NS + k) * cs + cell] = d->newton_factor_wrt_strain_rate[((size_t)cell * NQ + q) * NS + k];
+        }
+        P[(size_t)q * cs + cell] = d->newton_factor_wrt_pressure[(size_t)cell * NQ + q];
+      }
+    CHECK(c->upload(&cd.nw_strain, E)); CHECK(c->upload(&cd.nw_dEde, D)); CHECK(c->upload(&cd.nw_dEdp, P));
+    cd.newton = true;
+    cd.nw_symmetrize = d->symmetrize_newton_system ? 1 : 0;
+    cd.bytes += (E.size() + D.size() + P.size()) * 8;
+  }
   cd.set = true;
   c->diag_ready = false; c->smoothers_ready = false;
   return 0;

@@ -55,6 +55,11 @@ struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
   int nqv = 0;
   double lambda = 1.0;
   int is_compressible = 0;
+  // Newton-derivative terms of the Stokes operator (active level only): tables [q][NS][cstride]
+  // (symmetric tensors unrolled: diagonal, then 01, 02, 12) and [q][cstride]
+  bool newton = false;
+  int nw_symmetrize = 0;
+  double *nw_strain = nullptr, *nw_dEde = nullptr, *nw_dEdp = nullptr;
   size_t bytes = 0;
 };
 

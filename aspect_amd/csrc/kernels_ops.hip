@@ -89,6 +89,10 @@ struct CellArgs {
   double lambda;
   const double *src_u, *src_p;
   double *slots_u, *slots_p;
+  // Newton-derivative tables (Stokes operator, active level): symmetric tensors unrolled
+  // (diagonal, then 01, 02, 12): [q][NS][cstride]; pressure factor [q][cstride]
+  const double *nw_strain, *nw_dEde, *nw_dEdp;
+  int nw_symmetrize;
 };
 
 enum { KOP_STOKES = 0, KOP_A = 1, KOP_BT = 2 };
@@ -120,7 +124,9 @@ template <int DIM> struct KDims {
 // GATHER: read the cell's velocity values from global memory here; otherwise the caller has
 // filled u[] (the block kernel gathers from an LDS copy of the block's nodes).
 // GEN: general (MappingQ) geometry: full inverse Jacobian and JxW per q-point instead of cell extents.
-template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN>
+// NEWTON (Stokes only): the Newton-derivative terms of matrix_free_operators.cc:196-213, 249-258:
+// three cell-wide sums over the q-points first, then an extra stress at every q-point.
+template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN, bool NEWTON = false>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, double (*xb)[KDims<DIM>::LROW], double *G,
                                              double *pout, const double *eta_tile, double *u) {
@@ -201,6 +207,88 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       for (int b = 0; b < NPLP; ++b) pz[z][b] = fma(n1(z, 0), pin[b], n1(z, 1) * pin[NPLP + b]);
   }
 
+  // ---- Newton: S1 = sum_q dEde_q : sym grad u_q, S3 = sum_q strain_q : sym grad u_q (a symmetric
+  // table tensor contracted with sym grad u only needs this lane's own gradient row; the rows of the
+  // DIM lanes of the cell are summed through the LDS tile), S2 = sum_q dEdp_q p_q
+  constexpr int NS = DIM * (DIM + 1) / 2;
+  int symidx[DIM];   // unrolled index of tensor entry (c, dd)
+#pragma unroll
+  for (int dd = 0; dd < DIM; ++dd) symidx[dd] = (dd == c) ? c : c + dd + (DIM == 3 ? 2 : 1);
+  (void)symidx;
+  double S1 = 0.0, S2 = 0.0, S3 = 0.0;
+  if (NEWTON) {
+#pragma unroll
+    for (int L = 0; L < NV / 3; ++L) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int qy = (DIM == 3) ? L % 3 : L, qz = (DIM == 3) ? L / 3 : 0;
+      const int base = 3 * L;
+      double d[DIM][3], pq[3];
+      {
+        double t0, t1;
+        if (DIM == 3) {
+          t0 = fma(n1(qy, 0), pz[qz][0], n1(qy, 1) * pz[qz][2]);
+          t1 = fma(n1(qy, 0), pz[qz][1], n1(qy, 1) * pz[qz][3]);
+        } else {
+          t0 = pz[qy][0];
+          t1 = pz[qy][1];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) pq[x] = fma(n1(x, 0), t0, n1(x, 1) * t1);
+      }
+      deriv3(u[base], u[base + 1], u[base + 2], d[0][0], d[0][1], d[0][2]);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+          if (dcol(qy, m) != 0.0) s1 = fma(dcol(qy, m), u[9 * qz + 3 * m + x], s1);
+        d[1][x] = s1;
+        if (DIM == 3) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            if (dcol(qz, m) != 0.0) s2 = fma(dcol(qz, m), u[9 * m + 3 * qy + x], s2);
+          d[DIM - 1][x] = s2;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const size_t q = (size_t)(base + x);
+        double g[DIM];
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) {
+          if (GEN) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < DIM; ++e) acc = fma(d[e][x], A.invJT[(q * (DIM * DIM) + e * DIM + dd) * cs + cell], acc);
+            g[dd] = INV_S * acc;
+          } else {
+            g[dd] = d[dd][x] * ih[dd];
+          }
+        }
+#pragma unroll
+        for (int dd = 0; dd < DIM; ++dd) {
+          S1 = fma(A.nw_dEde[(q * NS + symidx[dd]) * cs + cell], g[dd], S1);
+          if (A.nw_symmetrize) S3 = fma(A.nw_strain[(q * NS + symidx[dd]) * cs + cell], g[dd], S3);
+        }
+        S2 = fma(A.nw_dEdp[q * cs + cell], pq[x], S2);
+      }
+      // keep the lines apart (as in the main loop): without the pins the table loads of all
+      // lines are hoisted to the top and spill
+      asm volatile("" : "+v"(S1), "+v"(S2), "+v"(S3) : : "memory");
+    }
+    xb[0][lane] = S1;
+    xb[1][lane] = S3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    S1 = 0.0;
+    S3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) { S1 += xb[0][j * DIM + k]; S3 += xb[1][j * DIM + k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 #pragma unroll
   for (int a = 0; a < NV; ++a) G[a] = 0.0;
 #pragma unroll
@@ -315,6 +403,11 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
             tau[dd] = etaq * t[dd];
             if (COMP) tau[dd] = fma(-sel[dd] * (2.0 / 3.0) * etaq, div, tau[dd]);
             if (HAS_P) tau[dd] = fma(-sel[dd] * A.lambda, pq[x], tau[dd]);
+            if (NEWTON) {
+              const size_t qn = ((size_t)(base + x) * NS + symidx[dd]) * cs + cell;
+              const double e_cd = A.nw_strain[qn], d_cd = A.nw_dEde[qn];
+              tau[dd] += (A.nw_symmetrize ? e_cd * S1 + d_cd * S3 : 2.0 * e_cd * S1) + 2.0 * e_cd * S2;
+            }
           }
 #pragma unroll
           for (int e = 0; e < DIM; ++e) {
@@ -341,6 +434,12 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
             double F = (cw[dd] * f) * t[dd];
             if (COMP) F = fma(-compc[dd], fdiv, F);
             if (HAS_P) F = fma(-lamc[dd], wq * pq[x], F);
+            if (NEWTON) {
+              const size_t qn = ((size_t)(base + x) * NS + symidx[dd]) * cs + cell;
+              const double e_cd = A.nw_strain[qn], d_cd = A.nw_dEde[qn];
+              const double nw = (A.nw_symmetrize ? e_cd * S1 + d_cd * S3 : 2.0 * e_cd * S1) + 2.0 * e_cd * S2;
+              F = fma(ih[dd] * det * wq, nw, F);
+            }
             d[dd][x] = F;
           }
           if (OP == KOP_STOKES) {
@@ -430,8 +529,8 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 }
 
 // slot variant: every cell writes its contributions to slots [local dof][cell][component]
-template <int DIM, int OP, bool COMP, bool PERQ, bool GEN>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cells(const CellArgs A) {
+template <int DIM, int OP, bool COMP, bool PERQ, bool GEN, bool NEWTON = false>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, NEWTON ? 1 : AGMG_CELLS_WAVES) k_cells(const CellArgs A) {
   constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
   __shared__ double xbuf[WAVES_PER_BLOCK][3][LROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,7 +544,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES) k_cell
   const size_t cs = (size_t)A.cstride;
   double G[NV], pout[NP];
   double u[NV];
-  cell_compute<DIM, OP, COMP, PERQ, false, true, GEN>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, u);
+  cell_compute<DIM, OP, COMP, PERQ, false, true, GEN, NEWTON>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, u);
   if (valid) {
 #pragma unroll
     for (int a = 0; a < NV; ++a)
@@ -1060,6 +1159,10 @@ CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, 
   a.src_p = sp;
   a.slots_u = slu;
   a.slots_p = slp;
+  a.nw_strain = cd.nw_strain;
+  a.nw_dEde = cd.nw_dEde;
+  a.nw_dEdp = cd.nw_dEdp;
+  a.nw_symmetrize = cd.nw_symmetrize;
   return a;
 }
 
@@ -1076,7 +1179,20 @@ void launch_cells_t(hipStream_t s, const CellArgs &a, bool comp, bool perq) {
   }
 }
 template <int DIM, bool GEN>
-void launch_cells_op(hipStream_t s, const CellArgs &a, int which, bool comp, bool perq) {
+void launch_cells_newton(hipStream_t s, const CellArgs &a, bool comp, bool perq) {
+  const int cpb = (64 / DIM) * WAVES_PER_BLOCK;
+  const dim3 grid((a.n_cells + cpb - 1) / cpb), block(64 * WAVES_PER_BLOCK);
+  if (comp) {
+    if (perq) hipLaunchKernelGGL((k_cells<DIM, KOP_STOKES, true, true, GEN, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_cells<DIM, KOP_STOKES, true, false, GEN, true>), grid, block, 0, s, a);
+  } else {
+    if (perq) hipLaunchKernelGGL((k_cells<DIM, KOP_STOKES, false, true, GEN, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_cells<DIM, KOP_STOKES, false, false, GEN, true>), grid, block, 0, s, a);
+  }
+}
+template <int DIM, bool GEN>
+void launch_cells_op(hipStream_t s, const CellArgs &a, int which, bool comp, bool perq, bool newton) {
+  if (newton && which == AGMG_OP_STOKES) { launch_cells_newton<DIM, GEN>(s, a, comp, perq); return; }
   if (which == AGMG_OP_A) launch_cells_t<DIM, KOP_A, GEN>(s, a, comp, perq);
   else if (which == AGMG_OP_STOKES) launch_cells_t<DIM, KOP_STOKES, GEN>(s, a, comp, perq);
   else launch_cells_t<DIM, KOP_BT, GEN>(s, a, false, false);
@@ -1122,11 +1238,11 @@ int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, in
   const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
   const bool gen = L.geom == AGMG_GEOM_GENERAL;
   if (L.dim == 3) {
-    if (gen) launch_cells_op<3, true>(s, a, which, comp, perq);
-    else launch_cells_op<3, false>(s, a, which, comp, perq);
+    if (gen) launch_cells_op<3, true>(s, a, which, comp, perq, cd.newton);
+    else launch_cells_op<3, false>(s, a, which, comp, perq, cd.newton);
   } else {
-    if (gen) launch_cells_op<2, true>(s, a, which, comp, perq);
-    else launch_cells_op<2, false>(s, a, which, comp, perq);
+    if (gen) launch_cells_op<2, true>(s, a, which, comp, perq, cd.newton);
+    else launch_cells_op<2, false>(s, a, which, comp, perq, cd.newton);
   }
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1234,7 +1350,10 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
               const EpiArgs *ep) {
   // ep (Stokes, PH_ALL only): also finish the pressure rows (pull of slots_p with epilogue *ep)
   if (ep && (which != AGMG_OP_STOKES || phase != PH_ALL)) { set_error("launch_op: pressure epilogue misuse"); return -1; }
-  if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB)) {
+  // (the Newton-derivative variant of the Stokes cell kernel exists on the slot path only: it runs
+  // once per outer Krylov iteration)
+  if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB) ||
+      (cd.newton && which == AGMG_OP_STOKES)) {
     if (phase != PH_OWNED) {
       const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
       if (rc) return rc;

@@ -111,7 +111,15 @@ struct CellData {
   double lambda = 1.0;
   int nqv = 1;
   Vec eta;  // [n_cells][nqv]
+  // Newton tables (active level, local_smoothing.cc:447-663): symmetric tensors unrolled as deal.II
+  // does, diagonal first then (0,1), (0,2), (1,2); [n_cells][nq][dim(dim+1)/2] and [n_cells][nq]
+  Vec strain, dEde, dEdp;
 };
+inline int symc(int dim, int a, int b) {
+  if (a == b) return a;
+  if (a > b) std::swap(a, b);
+  return dim == 2 ? 2 : (a == 0 ? (b == 1 ? 3 : 4) : 5);
+}
 
 struct Level {
   int dim = 3, n_cells = 0, n_nodes_v = 0, n_nodes_p = 0;
@@ -231,6 +239,25 @@ void cell_apply(const Level &L, const CellData &cd, int cell, Mode mode,
   double tref[3][3][27];
   double ptest[27];
   const bool comp = cd.is_compressible || cd.dilation;
+  constexpr int NS = DIM * (DIM + 1) / 2;
+  // Newton derivative terms, matrix_free_operators.cc:196-213: three cell-wide sums over the
+  // q-points (no weights), used at every q-point below (:249-258)
+  double S1 = 0, S2 = 0, S3 = 0;
+  const bool newton = cd.newton && mode == M_STOKES;
+  if (newton)
+    for (int q = 0; q < NQ; ++q) {
+      Geo g; cell_geometry<DIM>(L, cell, q, g);
+      const double *de = &cd.dEde[(size_t(cell) * NQ + q) * NS], *st = &cd.strain[(size_t(cell) * NQ + q) * NS];
+      for (int c = 0; c < DIM; ++c)
+        for (int d = 0; d < DIM; ++d) {
+          double gcd = 0, gdc = 0;
+          for (int e = 0; e < DIM; ++e) { gcd += gref[c][e][q] * g.invJ[e][d]; gdc += gref[d][e][q] * g.invJ[e][c]; }
+          const double sym = 0.5 * (gcd + gdc);
+          S1 += de[symc(DIM, c, d)] * sym;
+          if (cd.symmetrize) S3 += st[symc(DIM, c, d)] * sym;
+        }
+      S2 += cd.dEdp[size_t(cell) * NQ + q] * pq[q];
+    }
   for (int q = 0; q < NQ; ++q) {
     Geo g; cell_geometry<DIM>(L, cell, q, g);
     const double eta2 = 2.0 * cd.eta[size_t(cell) * cd.nqv + (cd.nqv == 1 ? 0 : q)];
@@ -259,6 +286,14 @@ void cell_apply(const Level &L, const CellData &cd, int cell, Mode mode,
     if (mode != M_A) {
       for (int d = 0; d < DIM; ++d) tau[d][d] -= cd.lambda * pq[q];
       if (mode == M_STOKES) ptest[q] = -cd.lambda * div * g.jxw;
+    }
+    if (newton) {
+      const double *de = &cd.dEde[(size_t(cell) * NQ + q) * NS], *st = &cd.strain[(size_t(cell) * NQ + q) * NS];
+      for (int c = 0; c < DIM; ++c)
+        for (int d = 0; d < DIM; ++d) {
+          const double e_cd = st[symc(DIM, c, d)], d_cd = de[symc(DIM, c, d)];
+          tau[c][d] += (cd.symmetrize ? e_cd * S1 + d_cd * S3 : 2.0 * e_cd * S1) + 2.0 * e_cd * S2;
+        }
     }
     for (int c = 0; c < DIM; ++c)
       for (int e = 0; e < DIM; ++e) {
@@ -390,6 +425,68 @@ void dense_cell_matrix(const Level &L, const CellData &cd, int cell, std::vector
     }
   }
 }
+// Newton terms of the dense cell matrix: column j of the extra block is
+//   sum_q [ (2 E_q S1_j | E_q S1_j + D_q S3_j) + 2 E_q S2_j ] : eps_q(phi_i) JxW_q
+// with the cell-wide sums S1_j = sum_q' D_q' : eps_q'(phi_j), S3_j = sum_q' E_q' : eps_q'(phi_j)
+// (velocity columns) and S2_j = sum_q' dEdp_q' psi_j(q') (pressure columns)
+template <int DIM>
+void dense_newton_terms(const Level &L, const CellData &cd, int cell, std::vector<double> &K) {
+  const int NV = L.nv, NP = L.np, NQ = L.nq, ND = DIM * NV + NP;
+  constexpr int NS = DIM * (DIM + 1) / 2;
+  std::vector<double> gphi(size_t(NQ) * NV * DIM), psi(size_t(NQ) * NP), jxw(NQ);
+  for (int q = 0; q < NQ; ++q) {
+    Geo g; cell_geometry<DIM>(L, cell, q, g);
+    jxw[q] = g.jxw;
+    int qi[3] = {q % 3, (q / 3) % 3, q / 9};
+    for (int i = 0; i < NV; ++i) {
+      int ii[3] = {i % 3, (i / 3) % 3, i / 9};
+      double gr[3];
+      for (int e = 0; e < DIM; ++e) {
+        double v = 1;
+        for (int d = 0; d < DIM; ++d) v *= (d == e ? T.D2[qi[d]][ii[d]] : T.N2[qi[d]][ii[d]]);
+        gr[e] = v;
+      }
+      for (int d = 0; d < DIM; ++d) {
+        double s = 0;
+        for (int e = 0; e < DIM; ++e) s += gr[e] * g.invJ[e][d];
+        gphi[(size_t(q) * NV + i) * DIM + d] = s;
+      }
+    }
+    for (int i = 0; i < NP; ++i) {
+      int ii[3] = {i % 2, (i / 2) % 2, i / 4};
+      double v = 1;
+      for (int d = 0; d < DIM; ++d) v *= T.N1[qi[d]][ii[d]];
+      psi[size_t(q) * NP + i] = v;
+    }
+  }
+  // table tensor : eps_q(phi_(i,c))
+  auto contract = [&](const double *t, int q, int i, int c) {
+    double s = 0;
+    for (int b = 0; b < DIM; ++b) s += t[symc(DIM, c, b)] * gphi[(size_t(q) * NV + i) * DIM + b];
+    return s;   // T symmetric: T : sym(grad) = sum_b T_cb d_b phi
+  };
+  std::vector<double> colS1(ND, 0.0), colS3(ND, 0.0), colS2(ND, 0.0);
+  for (int q = 0; q < NQ; ++q) {
+    const double *de = &cd.dEde[(size_t(cell) * NQ + q) * NS], *st = &cd.strain[(size_t(cell) * NQ + q) * NS];
+    for (int j = 0; j < NV; ++j) for (int c2 = 0; c2 < DIM; ++c2) {
+      colS1[c2 * NV + j] += contract(de, q, j, c2);
+      colS3[c2 * NV + j] += contract(st, q, j, c2);
+    }
+    for (int j = 0; j < NP; ++j) colS2[DIM * NV + j] += cd.dEdp[size_t(cell) * NQ + q] * psi[size_t(q) * NP + j];
+  }
+  for (int q = 0; q < NQ; ++q) {
+    const double *de = &cd.dEde[(size_t(cell) * NQ + q) * NS], *st = &cd.strain[(size_t(cell) * NQ + q) * NS];
+    for (int i = 0; i < NV; ++i) for (int c = 0; c < DIM; ++c) {
+      const double Ei = contract(st, q, i, c), Di = contract(de, q, i, c);
+      const int row = c * NV + i;
+      for (int col = 0; col < ND; ++col) {
+        const double v = (cd.symmetrize ? Ei * colS1[col] + Di * colS3[col] : 2.0 * Ei * colS1[col]) + 2.0 * Ei * colS2[col];
+        K[size_t(row) * ND + col] += v * jxw[q];
+      }
+    }
+  }
+}
+
 template <int DIM>
 void dense_mass_matrix(const Level &L, const CellData &cd, int cell, std::vector<double> &K) {
   const int NP = L.np, NQ = L.nq;
@@ -431,6 +528,7 @@ void dense_vmult(const Level &L, const CellData &cd, int which, const double *sr
       continue;
     }
     dense_cell_matrix<DIM>(L, cd, cell, K);
+    if (cd.newton && which == AGMG_OP_STOKES) dense_newton_terms<DIM>(L, cd, cell, K);
     std::vector<double> x(ND, 0.0), y(ND, 0.0);
     if (which != AGMG_OP_BT)
       for (int i = 0; i < NV; ++i) for (int c = 0; c < DIM; ++c)
@@ -1182,8 +1280,17 @@ int oracle_set_coefficients(oracle_ctx *o, int level, const agmg_cell_data *d) {
   int nc;
   if (level == AGMG_ACTIVE) { cd = &C.active_cd; nc = C.fin().n_cells; }
   else { cd = &C.levels[level].cd; nc = C.levels[level].n_cells; }
-  if (d->enable_newton_derivatives || d->enable_prescribed_dilation) { g_error = "Newton/dilation terms not implemented"; return -1; }
+  if (d->enable_prescribed_dilation) { g_error = "dilation terms not implemented"; return -1; }
   cd->is_compressible = d->is_compressible; cd->newton = 0; cd->dilation = 0; cd->symmetrize = d->symmetrize_newton_system;
+  if (d->enable_newton_derivatives) {  // active level only (local_smoothing.cc:447-663)
+    if (level != AGMG_ACTIVE) { g_error = "Newton tables exist on the active level only"; return -1; }
+    if (!d->strain_rate_table || !d->newton_factor_wrt_strain_rate || !d->newton_factor_wrt_pressure) { g_error = "Newton tables missing"; return -1; }
+    const int dim = C.opt.dim, nq = ipow(3, dim), ns = dim * (dim + 1) / 2;
+    cd->strain.assign(d->strain_rate_table, d->strain_rate_table + size_t(nc) * nq * ns);
+    cd->dEde.assign(d->newton_factor_wrt_strain_rate, d->newton_factor_wrt_strain_rate + size_t(nc) * nq * ns);
+    cd->dEdp.assign(d->newton_factor_wrt_pressure, d->newton_factor_wrt_pressure + size_t(nc) * nq);
+    cd->newton = 1;
+  }
   cd->lambda = d->pressure_scaling; cd->nqv = d->n_q_viscosity;
   cd->eta.assign(d->viscosity, d->viscosity + size_t(nc) * cd->nqv);
   cd->set = true;

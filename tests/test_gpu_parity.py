@@ -102,6 +102,57 @@ def test_vmult_compressible(pair):
     assert relerr(comp, g.vmult(capi.OP_A, src)) > 1e-3
 
 
+@pytest.mark.parametrize("symmetrize", [0, 1])
+def test_vmult_newton_derivatives(pair, symmetrize):
+    """StokesOperator with enable_newton_derivatives (matrix_free_operators.cc:196-213, 249-258):
+    random strain-rate / derivative tables on the active level, both symmetrisation modes.  The
+    reference holds no vector for it; the oracle's two formulations (sum-factorised and dense)
+    agree to 1e-13 in the CPU suite."""
+    p, g, o = pair
+    fin = p.hier.finest
+    nq, ns = 3 ** p.dim, p.dim * (p.dim + 1) // 2
+    rng = np.random.Generator(np.random.PCG64(41))
+    scale = float(np.mean(p.eta_active))
+    newton = (rng.uniform(-1, 1, (fin.n_cells, nq, ns)), scale * rng.uniform(-1, 1, (fin.n_cells, nq, ns)),
+              scale * rng.uniform(-1, 1, (fin.n_cells, nq)))
+    try:
+        for s in (g, o):
+            s._set_coeff(capi.ACTIVE, p.eta_active, newton=newton, symmetrize=symmetrize)
+        src = rand_vec(g.size(capi.OP_STOKES), 43, fin)
+        a, b = g.vmult(capi.OP_STOKES, src), o.vmult(capi.OP_STOKES, src)
+        assert relerr(a, b) < RTOL
+        # the A block and B^T of the active level carry no Newton terms
+        for which in (capi.OP_A, capi.OP_BT):
+            assert relerr(g.vmult(which, src[:g.size(which)]), o.vmult(which, src[:o.size(which)])) < RTOL
+    finally:
+        for s in (g, o):
+            s._set_coeff(capi.ACTIVE, p.eta_active)
+            s._check(s.lib.compute_diagonals(s.ctx))
+    assert relerr(a, g.vmult(capi.OP_STOKES, src)) > 1e-6    # the terms are there
+
+
+def test_newton_system_solve(hip_lib, oracle_lib):
+    """solve(solve_newton_system = true) with Newton-derivative terms in the Stokes operator and the
+    Picard block preconditioner (local_smoothing.cc:1169-1183): same iteration count and solution."""
+    p = cases.nsinker_box(2, n_sinkers=4, ratio=1e2, averaging=bm.AVG_NONE)
+    g, o = make_pair(p, hip_lib, oracle_lib)
+    fin = p.hier.finest
+    rng = np.random.Generator(np.random.PCG64(5))
+    eta = p.eta_active
+    strain = rng.uniform(-1, 1, (fin.n_cells, 27, 6))
+    newton = (strain, -0.05 * eta[:, :, None] * strain, np.zeros((fin.n_cells, 27)))
+    for s in (g, o):
+        s._set_coeff(capi.ACTIVE, eta, newton=newton, symmetrize=1)
+        s._check(s.lib.compute_diagonals(s.ctx))     # assemble -> build_preconditioner
+    xg, rg, _ = g.solve(newton=True)
+    xo, ro, _ = o.solve(newton=True)
+    assert abs(rg.n_cheap_iterations - ro.n_cheap_iterations) <= 1 and rg.n_expensive_iterations == 0
+    assert abs(rg.solver_tolerance - ro.solver_tolerance) <= 1e-10 * ro.solver_tolerance
+    nu = fin.n_dofs_v
+    assert relerr(xg[:nu], xo[:nu]) < 1e-4
+    g.close(); o.close()
+
+
 def test_inverse_diagonals(pair):
     p, g, o = pair
     for level in range(p.hier.n_levels):

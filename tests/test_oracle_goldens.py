@@ -186,3 +186,29 @@ def test_periodic_box_tables_transfer_and_solve():
     x, rep, rc = s.solve()
     assert rc == 0 and rep.n_cheap_iterations <= 20 and rep.final_linear_residual <= rep.solver_tolerance
     s.close()
+
+
+@pytest.mark.parametrize("make", [
+    lambda: cases.nsinker_box(1, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE),
+    lambda: cases.solcx(2),
+    lambda: cases.deformed_sinker_box(3, 1),
+])
+@pytest.mark.parametrize("symmetrize", [0, 1])
+def test_newton_derivative_terms_equal_dense_form(make, symmetrize):
+    """StokesOperator with enable_newton_derivatives (matrix_free_operators.cc:196-213, 249-258):
+    the cell-wide sums over the q-points restated twice, sum-factorised and as a dense cell matrix.
+    Unpinned by the reference (its Newton GMG tests need the nonlinear material models)."""
+    p = make().build()
+    s = pyoracle.solver(p)
+    fin = p.hier.finest
+    nq, ns = 3 ** p.dim, p.dim * (p.dim + 1) // 2
+    rng = np.random.Generator(np.random.PCG64(17))
+    newton = (rng.uniform(-1, 1, (fin.n_cells, nq, ns)), rng.uniform(-1, 1, (fin.n_cells, nq, ns)),
+              rng.uniform(-1, 1, (fin.n_cells, nq)))
+    src = rng.uniform(-1, 1, s.size(capi.OP_STOKES))
+    plain = s.vmult(capi.OP_STOKES, src)
+    s._set_coeff(capi.ACTIVE, p.eta_active, newton=newton, symmetrize=symmetrize)
+    a, b = s.vmult(capi.OP_STOKES, src), s.vmult(capi.OP_STOKES, src, dense=True)
+    assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(b)
+    assert np.linalg.norm(a - plain) > 1e-9 * np.linalg.norm(plain)
+    s.close()
