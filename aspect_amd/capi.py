@@ -65,6 +65,8 @@ class CellData(C.Structure):
         ("n_q_viscosity", C.c_int32), ("viscosity", c_dp),
         ("strain_rate_table", c_dp), ("newton_factor_wrt_strain_rate", c_dp),
         ("newton_factor_wrt_pressure", c_dp),
+        ("dilation_lhs_term", c_dp), ("dilation_derivative_wrt_strain_rate", c_dp),
+        ("dilation_derivative_wrt_pressure", c_dp),
     ]
 
 
@@ -271,7 +273,7 @@ class Solver:
         self._check(self.lib.set_level(self.ctx, l, C.byref(d)))
         self._keep.append(keep)
 
-    def _set_coeff(self, l, table, is_compressible=0, newton=None, symmetrize=0):
+    def _set_coeff(self, l, table, is_compressible=0, newton=None, symmetrize=0, dilation=None):
         """newton = (strain_rate [cells][nq][ns], newton_factor_wrt_strain_rate [cells][nq][ns],
         newton_factor_wrt_pressure [cells][nq]): enables the Newton-derivative terms (active level)."""
         t = np.ascontiguousarray(table, dtype=np.float64)
@@ -284,6 +286,13 @@ class Solver:
             cd.strain_rate_table = _ptr(nt[0], C.c_double)
             cd.newton_factor_wrt_strain_rate = _ptr(nt[1], C.c_double)
             cd.newton_factor_wrt_pressure = _ptr(nt[2], C.c_double)
+        if dilation is not None:   # (lhs term [cells][nq], d/d strain rate [cells][nq][ns] | None, d/dp [cells][nq] | None)
+            dt = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in dilation]
+            cd.enable_prescribed_dilation = 1
+            cd.dilation_lhs_term = _ptr(dt[0], C.c_double)
+            if len(dt) > 1 and dt[1] is not None:
+                cd.dilation_derivative_wrt_strain_rate = _ptr(dt[1], C.c_double)
+                cd.dilation_derivative_wrt_pressure = _ptr(dt[2], C.c_double)
         cd.pressure_scaling = self.problem.pressure_scaling
         cd.n_q_viscosity = t.shape[1]
         cd.viscosity = _ptr(t, C.c_double)

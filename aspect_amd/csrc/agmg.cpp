@@ -1456,6 +1456,7 @@ void agmg_destroy(agmg_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto &l : c->L) c->free_level(l);
   c->dfree(c->active.etaT); c->dfree(c->active.nw_strain); c->dfree(c->active.nw_dEde); c->dfree(c->active.nw_dEdp);
+  c->dfree(c->active.dil_lhs); c->dfree(c->active.dil_de); c->dfree(c->active.dil_dp);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
   for (int w = 0; w < 2; ++w)
     for (auto *v : {&c->mg_def[w], &c->mg_sol[w], &c->mg_tmp[w], &c->mg_t[w]})
@@ -1634,9 +1635,9 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
 int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   if (!c || !d) { set_error("null argument"); return -1; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
-  if (d->enable_prescribed_dilation) {
-    set_error("prescribed-dilation terms are not built (SURVEY.md 8f3)");
-    return -2;
+  if (d->enable_prescribed_dilation) {   // active level only (local_smoothing.cc:456-462)
+    if (level != AGMG_ACTIVE) { set_error("prescribed-dilation tables belong to the active level (AGMG_ACTIVE)"); return -1; }
+    if (!d->dilation_lhs_term) { set_error("dilation_lhs_term missing"); return -1; }
   }
   if (d->enable_newton_derivatives) {
     // the tables exist on the active level only (local_smoothing.cc:447-663); the level operators
@@ -1684,6 +1685,28 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
     cd.newton = true;
     cd.nw_symmetrize = d->symmetrize_newton_system ? 1 : 0;
     cd.bytes += (E.size() + D.size() + P.size()) * 8;
+  }
+  c->dfree(cd.dil_lhs); c->dfree(cd.dil_de); c->dfree(cd.dil_dp);
+  cd.dilation = false;
+  if (d->enable_prescribed_dilation) {
+    const int dim = c->opt.dim, NS = dim * (dim + 1) / 2;
+    std::vector<double> Lh((size_t)NQ * cs, 0.0);
+    for (int cell = 0; cell < lv.n_cells; ++cell)
+      for (int q = 0; q < NQ; ++q) Lh[(size_t)q * cs + cell] = d->dilation_lhs_term[(size_t)cell * NQ + q];
+    CHECK(c->upload(&cd.dil_lhs, Lh));
+    cd.bytes += Lh.size() * 8;
+    if (d->enable_newton_derivatives && d->dilation_derivative_wrt_strain_rate && d->dilation_derivative_wrt_pressure) {
+      std::vector<double> De((size_t)NQ * NS * cs, 0.0), Dp((size_t)NQ * cs, 0.0);
+      for (int cell = 0; cell < lv.n_cells; ++cell)
+        for (int q = 0; q < NQ; ++q) {
+          for (int k = 0; k < NS; ++k)
+            De[((size_t)q * NS + k) * cs + cell] = d->dilation_derivative_wrt_strain_rate[((size_t)cell * NQ + q) * NS + k];
+          Dp[(size_t)q * cs + cell] = d->dilation_derivative_wrt_pressure[(size_t)cell * NQ + q];
+        }
+      CHECK(c->upload(&cd.dil_de, De)); CHECK(c->upload(&cd.dil_dp, Dp));
+      cd.bytes += (De.size() + Dp.size()) * 8;
+    }
+    cd.dilation = true;
   }
   cd.set = true;
   c->diag_ready = false; c->smoothers_ready = false;

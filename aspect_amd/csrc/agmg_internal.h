@@ -60,6 +60,9 @@ struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
   bool newton = false;
   int nw_symmetrize = 0;
   double *nw_strain = nullptr, *nw_dEde = nullptr, *nw_dEdp = nullptr;
+  // prescribed dilation (active level only): LHS term [q][cstride], with Newton its derivatives
+  bool dilation = false;
+  double *dil_lhs = nullptr, *dil_de = nullptr, *dil_dp = nullptr;
   size_t bytes = 0;
 };
 

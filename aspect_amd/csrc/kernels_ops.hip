@@ -92,7 +92,10 @@ struct CellArgs {
   // Newton-derivative tables (Stokes operator, active level): symmetric tensors unrolled
   // (diagonal, then 01, 02, 12): [q][NS][cstride]; pressure factor [q][cstride]
   const double *nw_strain, *nw_dEde, *nw_dEdp;
-  int nw_symmetrize;
+  int nw_on, nw_symmetrize;
+  // prescribed dilation (Stokes operator, active level): LHS term [q][cstride]; with Newton
+  // derivatives d/d(strain rate) [q][NS][cstride] and d/dp [q][cstride] (or nullptr)
+  const double *dil_lhs, *dil_de, *dil_dp;
 };
 
 enum { KOP_STOKES = 0, KOP_A = 1, KOP_BT = 2 };
@@ -124,8 +127,10 @@ template <int DIM> struct KDims {
 // GATHER: read the cell's velocity values from global memory here; otherwise the caller has
 // filled u[] (the block kernel gathers from an LDS copy of the block's nodes).
 // GEN: general (MappingQ) geometry: full inverse Jacobian and JxW per q-point instead of cell extents.
-// NEWTON (Stokes only): the Newton-derivative terms of matrix_free_operators.cc:196-213, 249-258:
-// three cell-wide sums over the q-points first, then an extra stress at every q-point.
+// NEWTON (Stokes only): the optional terms of StokesOperator::local_apply, selected at run time by
+// A.nw_on (Newton derivatives, matrix_free_operators.cc:196-213, 249-258: three cell-wide sums over
+// the q-points first, then an extra stress at every q-point) and A.dil_lhs (prescribed dilation,
+// :230-234, 259-268: extra terms in the pressure rows).
 template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN, bool NEWTON = false>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, double (*xb)[KDims<DIM>::LROW], double *G,
@@ -216,7 +221,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
   for (int dd = 0; dd < DIM; ++dd) symidx[dd] = (dd == c) ? c : c + dd + (DIM == 3 ? 2 : 1);
   (void)symidx;
   double S1 = 0.0, S2 = 0.0, S3 = 0.0;
-  if (NEWTON) {
+  if (NEWTON && A.nw_on) {
 #pragma unroll
     for (int L = 0; L < NV / 3; ++L) {
       __builtin_amdgcn_sched_barrier(0);
@@ -383,9 +388,13 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       const double f = wq * etav;
       if (HAS_U) {
         // column c of the velocity gradient: du_dd/dx_c lives in the lane of component dd
-        double t[DIM];
+        double t[DIM], grow[DIM];   // grow: this lane's own physical gradient row (dilation derivative)
 #pragma unroll
-        for (int dd = 0; dd < DIM; ++dd) t[dd] = d[dd][x] + xb[x][(j * DIM + dd) * DIM + c];
+        for (int dd = 0; dd < DIM; ++dd) {
+          grow[dd] = d[dd][x];
+          t[dd] = d[dd][x] + xb[x][(j * DIM + dd) * DIM + c];
+        }
+        (void)grow;
         double fdiv = 0.0, div = 0.0;
         if (COMP) {
 #pragma unroll
@@ -403,7 +412,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
             tau[dd] = etaq * t[dd];
             if (COMP) tau[dd] = fma(-sel[dd] * (2.0 / 3.0) * etaq, div, tau[dd]);
             if (HAS_P) tau[dd] = fma(-sel[dd] * A.lambda, pq[x], tau[dd]);
-            if (NEWTON) {
+            if (NEWTON && A.nw_on) {
               const size_t qn = ((size_t)(base + x) * NS + symidx[dd]) * cs + cell;
               const double e_cd = A.nw_strain[qn], d_cd = A.nw_dEde[qn];
               tau[dd] += (A.nw_symmetrize ? e_cd * S1 + d_cd * S3 : 2.0 * e_cd * S1) + 2.0 * e_cd * S2;
@@ -428,13 +437,25 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
             for (int dd = 0; dd < DIM; ++dd) s = fma(sel[dd], t[dd], s);
             pt[x] = (-0.5 * A.lambda * jxw) * s;
           }
+          if (NEWTON && A.dil_lhs) {   // pressure rows of the prescribed dilation (lane 0 carries the p terms)
+            const size_t q = (size_t)(base + x);
+            double extra = (c == 0) ? -A.lambda * A.lambda * A.dil_lhs[q * cs + cell] * pq[x] : 0.0;
+            if (A.nw_on && A.dil_de) {
+              double s = 0.0;
+#pragma unroll
+              for (int dd = 0; dd < DIM; ++dd) s = fma(A.dil_de[(q * NS + symidx[dd]) * cs + cell], grow[dd], s);
+              extra += A.lambda * s;
+              if (c == 0) extra += A.lambda * A.lambda * A.dil_dp[q * cs + cell] * pq[x];
+            }
+            pt[x] = fma(jxw, extra, pt[x]);
+          }
         } else {
 #pragma unroll
           for (int dd = 0; dd < DIM; ++dd) {
             double F = (cw[dd] * f) * t[dd];
             if (COMP) F = fma(-compc[dd], fdiv, F);
             if (HAS_P) F = fma(-lamc[dd], wq * pq[x], F);
-            if (NEWTON) {
+            if (NEWTON && A.nw_on) {
               const size_t qn = ((size_t)(base + x) * NS + symidx[dd]) * cs + cell;
               const double e_cd = A.nw_strain[qn], d_cd = A.nw_dEde[qn];
               const double nw = (A.nw_symmetrize ? e_cd * S1 + d_cd * S3 : 2.0 * e_cd * S1) + 2.0 * e_cd * S2;
@@ -447,6 +468,18 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
             for (int dd = 0; dd < DIM; ++dd) s = fma(ptc[dd], t[dd], s);
             pt[x] = wq * s;
+            if (NEWTON && A.dil_lhs) {
+              const size_t q = (size_t)(base + x);
+              double extra = (c == 0) ? -A.lambda * A.lambda * A.dil_lhs[q * cs + cell] * pq[x] : 0.0;
+              if (A.nw_on && A.dil_de) {
+                double sd = 0.0;
+#pragma unroll
+                for (int dd = 0; dd < DIM; ++dd) sd = fma(A.dil_de[(q * NS + symidx[dd]) * cs + cell], grow[dd], sd);
+                extra += A.lambda * sd;
+                if (c == 0) extra += A.lambda * A.lambda * A.dil_dp[q * cs + cell] * pq[x];
+              }
+              pt[x] = fma(wq * det, extra, pt[x]);
+            }
           }
         }
       } else if (GEN) {
@@ -1163,6 +1196,10 @@ CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, 
   a.nw_dEde = cd.nw_dEde;
   a.nw_dEdp = cd.nw_dEdp;
   a.nw_symmetrize = cd.nw_symmetrize;
+  a.nw_on = cd.newton ? 1 : 0;
+  a.dil_lhs = cd.dilation ? cd.dil_lhs : nullptr;
+  a.dil_de = cd.dil_de;
+  a.dil_dp = cd.dil_dp;
   return a;
 }
 
@@ -1235,14 +1272,14 @@ int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, in
   const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
   const bool perq = cd.nqv > 1;
   // the compressible term only exists where the velocity is read (A, Stokes)
-  const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
+  const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;
   const bool gen = L.geom == AGMG_GEOM_GENERAL;
   if (L.dim == 3) {
-    if (gen) launch_cells_op<3, true>(s, a, which, comp, perq, cd.newton);
-    else launch_cells_op<3, false>(s, a, which, comp, perq, cd.newton);
+    if (gen) launch_cells_op<3, true>(s, a, which, comp, perq, cd.newton || cd.dilation);
+    else launch_cells_op<3, false>(s, a, which, comp, perq, cd.newton || cd.dilation);
   } else {
-    if (gen) launch_cells_op<2, true>(s, a, which, comp, perq, cd.newton);
-    else launch_cells_op<2, false>(s, a, which, comp, perq, cd.newton);
+    if (gen) launch_cells_op<2, true>(s, a, which, comp, perq, cd.newton || cd.dilation);
+    else launch_cells_op<2, false>(s, a, which, comp, perq, cd.newton || cd.dilation);
   }
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1353,7 +1390,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
   // (the Newton-derivative variant of the Stokes cell kernel exists on the slot path only: it runs
   // once per outer Krylov iteration)
   if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB) ||
-      (cd.newton && which == AGMG_OP_STOKES)) {
+      ((cd.newton || cd.dilation) && which == AGMG_OP_STOKES)) {
     if (phase != PH_OWNED) {
       const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
       if (rc) return rc;
@@ -1385,7 +1422,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
 #endif
   BlkArgs b{dbg_buf, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), bt.lidT, slots_u};
   const bool perq = cd.nqv > 1;
-  const bool comp = cd.is_compressible != 0 && which != AGMG_OP_BT;
+  const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;
   const int lds = bt.max_unodes;
   const bool gen = L.geom == AGMG_GEOM_GENERAL;
   int rc;

@@ -159,10 +159,16 @@ typedef struct agmg_cell_data {
   double  pressure_scaling;
   int32_t n_q_viscosity;          /* second extent of the viscosity table: 1 or 3^dim */
   const double *viscosity;        /* [n_cells][n_q_viscosity] */
-  /* Newton tables (active level only, local_smoothing.cc:447-663), or NULL */
+  /* Newton tables (active level only, local_smoothing.cc:447-663), or NULL.  Symmetric tensors
+   * are unrolled as deal.II does: diagonal first, then (0,1), (0,2), (1,2). */
   const double *strain_rate_table;                 /* [n_cells][nq][dim(dim+1)/2] */
   const double *newton_factor_wrt_strain_rate;     /* [n_cells][nq][dim(dim+1)/2] */
   const double *newton_factor_wrt_pressure;        /* [n_cells][nq] */
+  /* prescribed plastic dilation (active level only, local_smoothing.cc:503-510, 632-643): the
+   * LHS term, and with Newton derivatives its two derivative tables; or NULL */
+  const double *dilation_lhs_term;                       /* [n_cells][nq] */
+  const double *dilation_derivative_wrt_strain_rate;     /* [n_cells][nq][dim(dim+1)/2] */
+  const double *dilation_derivative_wrt_pressure;        /* [n_cells][nq] */
 } agmg_cell_data;
 
 /* Mirrors the screen/statistics output of solve()

@@ -114,6 +114,8 @@ struct CellData {
   // Newton tables (active level, local_smoothing.cc:447-663): symmetric tensors unrolled as deal.II
   // does, diagonal first then (0,1), (0,2), (1,2); [n_cells][nq][dim(dim+1)/2] and [n_cells][nq]
   Vec strain, dEde, dEdp;
+  // prescribed dilation (active level): LHS term [n_cells][nq]; with Newton its derivatives
+  Vec dil_lhs, dil_de, dil_dp;
 };
 inline int symc(int dim, int a, int b) {
   if (a == b) return a;
@@ -285,7 +287,22 @@ void cell_apply(const Level &L, const CellData &cd, int cell, Mode mode,
     }
     if (mode != M_A) {
       for (int d = 0; d < DIM; ++d) tau[d][d] -= cd.lambda * pq[q];
-      if (mode == M_STOKES) ptest[q] = -cd.lambda * div * g.jxw;
+      if (mode == M_STOKES) {
+        double pterm = -cd.lambda * div;                                  // matrix_free_operators.cc:227-228
+        if (cd.dilation) pterm -= cd.lambda * cd.lambda * cd.dil_lhs[size_t(cell) * NQ + q] * pq[q];   // :230-234
+        if (cd.dilation && newton && !cd.dil_de.empty()) {                // :259-268
+          const double *dd = &cd.dil_de[(size_t(cell) * NQ + q) * NS];
+          double s = 0;
+          for (int c = 0; c < DIM; ++c)
+            for (int d = 0; d < DIM; ++d) {
+              double gcd = 0, gdc = 0;
+              for (int e = 0; e < DIM; ++e) { gcd += gref[c][e][q] * g.invJ[e][d]; gdc += gref[d][e][q] * g.invJ[e][c]; }
+              s += dd[symc(DIM, c, d)] * 0.5 * (gcd + gdc);
+            }
+          pterm += (s + cd.dil_dp[size_t(cell) * NQ + q] * cd.lambda * pq[q]) * cd.lambda;
+        }
+        ptest[q] = pterm * g.jxw;
+      }
     }
     if (newton) {
       const double *de = &cd.dEde[(size_t(cell) * NQ + q) * NS], *st = &cd.strain[(size_t(cell) * NQ + q) * NS];
@@ -423,6 +440,9 @@ void dense_cell_matrix(const Level &L, const CellData &cd, int cell, std::vector
         K[size_t(DIM * NV + j) * ND + row] += -cd.lambda * psi[j] * divi * g.jxw;
       }
     }
+    if (cd.dilation)   // - lambda^2 dilation_lhs p q
+      for (int i = 0; i < NP; ++i) for (int j = 0; j < NP; ++j)
+        K[size_t(DIM * NV + i) * ND + DIM * NV + j] += -cd.lambda * cd.lambda * cd.dil_lhs[size_t(cell) * NQ + q] * psi[i] * psi[j] * g.jxw;
   }
 }
 // Newton terms of the dense cell matrix: column j of the extra block is
@@ -474,6 +494,17 @@ void dense_newton_terms(const Level &L, const CellData &cd, int cell, std::vecto
     }
     for (int j = 0; j < NP; ++j) colS2[DIM * NV + j] += cd.dEdp[size_t(cell) * NQ + q] * psi[size_t(q) * NP + j];
   }
+  if (cd.dilation && !cd.dil_de.empty())   // pressure rows: lambda (D_q : eps_q(phi_j) + dDdp_q lambda psi_j) psi_i JxW
+    for (int q = 0; q < NQ; ++q) {
+      const double *dd = &cd.dil_de[(size_t(cell) * NQ + q) * NS];
+      for (int i = 0; i < NP; ++i) {
+        const double pi = psi[size_t(q) * NP + i] * jxw[q] * cd.lambda;
+        for (int j = 0; j < NV; ++j) for (int c2 = 0; c2 < DIM; ++c2)
+          K[size_t(DIM * NV + i) * ND + c2 * NV + j] += contract(dd, q, j, c2) * pi;
+        for (int j = 0; j < NP; ++j)
+          K[size_t(DIM * NV + i) * ND + DIM * NV + j] += cd.dil_dp[size_t(cell) * NQ + q] * cd.lambda * psi[size_t(q) * NP + j] * pi;
+      }
+    }
   for (int q = 0; q < NQ; ++q) {
     const double *de = &cd.dEde[(size_t(cell) * NQ + q) * NS], *st = &cd.strain[(size_t(cell) * NQ + q) * NS];
     for (int i = 0; i < NV; ++i) for (int c = 0; c < DIM; ++c) {
@@ -1280,8 +1311,19 @@ int oracle_set_coefficients(oracle_ctx *o, int level, const agmg_cell_data *d) {
   int nc;
   if (level == AGMG_ACTIVE) { cd = &C.active_cd; nc = C.fin().n_cells; }
   else { cd = &C.levels[level].cd; nc = C.levels[level].n_cells; }
-  if (d->enable_prescribed_dilation) { g_error = "dilation terms not implemented"; return -1; }
   cd->is_compressible = d->is_compressible; cd->newton = 0; cd->dilation = 0; cd->symmetrize = d->symmetrize_newton_system;
+  cd->dil_lhs.clear(); cd->dil_de.clear(); cd->dil_dp.clear();
+  if (d->enable_prescribed_dilation) {  // active level only (local_smoothing.cc:456-462)
+    if (level != AGMG_ACTIVE) { g_error = "dilation tables exist on the active level only"; return -1; }
+    if (!d->dilation_lhs_term) { g_error = "dilation_lhs_term missing"; return -1; }
+    const int dim = C.opt.dim, nq = ipow(3, dim), ns = dim * (dim + 1) / 2;
+    cd->dil_lhs.assign(d->dilation_lhs_term, d->dilation_lhs_term + size_t(nc) * nq);
+    if (d->enable_newton_derivatives && d->dilation_derivative_wrt_strain_rate && d->dilation_derivative_wrt_pressure) {
+      cd->dil_de.assign(d->dilation_derivative_wrt_strain_rate, d->dilation_derivative_wrt_strain_rate + size_t(nc) * nq * ns);
+      cd->dil_dp.assign(d->dilation_derivative_wrt_pressure, d->dilation_derivative_wrt_pressure + size_t(nc) * nq);
+    }
+    cd->dilation = 1;
+  }
   if (d->enable_newton_derivatives) {  // active level only (local_smoothing.cc:447-663)
     if (level != AGMG_ACTIVE) { g_error = "Newton tables exist on the active level only"; return -1; }
     if (!d->strain_rate_table || !d->newton_factor_wrt_strain_rate || !d->newton_factor_wrt_pressure) { g_error = "Newton tables missing"; return -1; }

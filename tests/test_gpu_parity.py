@@ -131,6 +131,36 @@ def test_vmult_newton_derivatives(pair, symmetrize):
     assert relerr(a, g.vmult(capi.OP_STOKES, src)) > 1e-6    # the terms are there
 
 
+@pytest.mark.parametrize("with_newton", [False, True])
+def test_vmult_prescribed_dilation(pair, with_newton):
+    """StokesOperator with enable_prescribed_dilation (matrix_free_operators.cc:230-234, 243-246,
+    259-268): LHS term in the pressure rows, deviatoric stress, and with Newton derivatives the
+    dilation derivative terms; the active A block becomes deviatoric too (:730-736)."""
+    p, g, o = pair
+    fin = p.hier.finest
+    nq, ns = 3 ** p.dim, p.dim * (p.dim + 1) // 2
+    rng = np.random.Generator(np.random.PCG64(47))
+    scale = float(np.mean(p.eta_active))
+    lam = p.pressure_scaling
+    newton = (rng.uniform(-1, 1, (fin.n_cells, nq, ns)), scale * rng.uniform(-1, 1, (fin.n_cells, nq, ns)),
+              scale * rng.uniform(-1, 1, (fin.n_cells, nq))) if with_newton else None
+    dil = (rng.uniform(0, 1, (fin.n_cells, nq)) / scale,) + \
+        ((rng.uniform(-1, 1, (fin.n_cells, nq, ns)), rng.uniform(-1, 1, (fin.n_cells, nq)) / lam) if with_newton else ())
+    try:
+        for s in (g, o):
+            s._set_coeff(capi.ACTIVE, p.eta_active, newton=newton, symmetrize=0, dilation=dil)
+        src = rand_vec(g.size(capi.OP_STOKES), 49, fin)
+        a, b = g.vmult(capi.OP_STOKES, src), o.vmult(capi.OP_STOKES, src)
+        assert relerr(a, b) < RTOL
+        nu = fin.n_dofs_v
+        assert relerr(g.vmult(capi.OP_A, src[:nu]), o.vmult(capi.OP_A, src[:nu])) < RTOL
+    finally:
+        for s in (g, o):
+            s._set_coeff(capi.ACTIVE, p.eta_active)
+            s._check(s.lib.compute_diagonals(s.ctx))
+    assert relerr(a, g.vmult(capi.OP_STOKES, src)) > 1e-6
+
+
 def test_newton_system_solve(hip_lib, oracle_lib):
     """solve(solve_newton_system = true) with Newton-derivative terms in the Stokes operator and the
     Picard block preconditioner (local_smoothing.cc:1169-1183): same iteration count and solution."""

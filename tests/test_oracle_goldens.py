@@ -211,4 +211,15 @@ def test_newton_derivative_terms_equal_dense_form(make, symmetrize):
     a, b = s.vmult(capi.OP_STOKES, src), s.vmult(capi.OP_STOKES, src, dense=True)
     assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(b)
     assert np.linalg.norm(a - plain) > 1e-9 * np.linalg.norm(plain)
+    # prescribed dilation (:230-234, 259-268), without and with its Newton derivative tables
+    dil = (rng.uniform(-1, 1, (fin.n_cells, nq)), rng.uniform(-1, 1, (fin.n_cells, nq, ns)),
+           rng.uniform(-1, 1, (fin.n_cells, nq)))
+    for kw in (dict(dilation=(dil[0],)), dict(newton=newton, symmetrize=symmetrize, dilation=dil)):
+        s._set_coeff(capi.ACTIVE, p.eta_active, **kw)
+        c, d = s.vmult(capi.OP_STOKES, src), s.vmult(capi.OP_STOKES, src, dense=True)
+        assert np.linalg.norm(c - d) <= 1e-13 * np.linalg.norm(d)
+        assert np.linalg.norm(c - a) > 1e-9 * np.linalg.norm(a)
+        nu = fin.n_dofs_v                      # the active A block becomes deviatoric
+        e, f = s.vmult(capi.OP_A, src[:nu]), s.vmult(capi.OP_A, src[:nu], dense=True)
+        assert np.linalg.norm(e - f) <= 1e-13 * np.linalg.norm(f)
     s.close()
