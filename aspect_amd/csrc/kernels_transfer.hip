@@ -86,45 +86,69 @@ struct RestrArgs {
   double *slots;              // coarse slots [a][cstride_c][NC]
 };
 
+template <int K> __host__ __device__ constexpr double pw(int r, int i) { return K == 2 ? p2row(r, i) : p1row(r, i); }
+
+// One lane per (parent cell, component): the (2K+1)^DIM patch values of the children are gathered
+// once (weighted by 1/multiplicity), then restricted by sum factorisation, (2K+1) -> (K+1) per
+// direction, plane by plane along the last axis.  (The first version looped over the patch once
+// per coarse local DoF: 27 x 27 dependent gathers per cell and component instead of 125.)
 template <int DIM, int K, int NC>
 __global__ void __launch_bounds__(256) k_restrict_cells(const RestrArgs A) {
-  constexpr int N1 = K + 1, NLOC = (DIM == 3) ? N1 * N1 * N1 : N1 * N1;
+  constexpr int N1 = K + 1, NF = 2 * K + 1, NLOC = (DIM == 3) ? N1 * N1 * N1 : N1 * N1, NCH = 1 << DIM;
+  constexpr int NZ = (DIM == 3) ? NF : 1, NZC = (DIM == 3) ? N1 : 1;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)A.n_coarse_cells * NLOC) return;
-  // cell fastest so that index loads and slot stores coalesce
-  const int a = (int)(t / A.n_coarse_cells), cell = (int)(t - (long)a * A.n_coarse_cells);
-  int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
-  double acc[NC];
-  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-  // patch rows with a non-zero weight for coarse index i (K = 2): i=0 -> {0,1,3}; 1 -> {1,2,3};
-  // 2 -> {1,3,4}; (K = 1): 0 -> {0,1}; 1 -> {1,2}.  Loop over all rows and skip zeros.
-  constexpr int NF = 2 * K + 1;
-  for (int r2 = 0; r2 < (DIM == 3 ? NF : 1); ++r2) {
-    const double w2 = (DIM == 3) ? prow<K>(r2, ai[2]) : 1.0;
-    if (w2 == 0.0) continue;
-    for (int r1 = 0; r1 < NF; ++r1) {
-      const double w1 = w2 * prow<K>(r1, ai[1]);
-      if (w1 == 0.0) continue;
+  if (t >= (long)A.n_coarse_cells * NC) return;
+  const int cell = (int)(t / NC), c = (int)(t - (long)cell * NC);
+  uint32_t ch[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) ch[k] = A.childrenT[(size_t)k * A.cstride_c + cell];
+  double acc[NLOC];
+#pragma unroll
+  for (int a = 0; a < NLOC; ++a) acc[a] = 0.0;
+#pragma unroll
+  for (int r2 = 0; r2 < NZ; ++r2) {
+    const int up2 = (DIM == 3 && r2 > K) ? 1 : 0;
+    // the plane's values: fine node at patch position (r0, r1, r2) lives in the child that is the
+    // upper half wherever r > K
+    double v[NF][NF];
+#pragma unroll
+    for (int r1 = 0; r1 < NF; ++r1)
+#pragma unroll
       for (int r0 = 0; r0 < NF; ++r0) {
-        const double w = w1 * prow<K>(r0, ai[0]);
-        if (w == 0.0) continue;
-        // fine node at patch position (r0, r1, r2): child = upper half where r > K
-        const int rr[3] = {r0, r1, r2};
-        int child = 0, loc = 0, stride = 1;
-        for (int d = 0; d < DIM; ++d) {
-          const int up = rr[d] > K ? 1 : 0;
-          child |= up << d;
-          loc += (rr[d] - K * up) * stride;
-          stride *= N1;
-        }
-        const uint32_t fcell = A.childrenT[(size_t)child * A.cstride_c + cell];
-        const uint32_t fn = A.cnfT[(size_t)loc * A.cstride_f + fcell] & NODE_MASK;
-        const double wm = w * A.inv_mult[fn];
-        for (int c = 0; c < NC; ++c) acc[c] = fma(wm, A.src[(size_t)fn * NC + c], acc[c]);
+        const int up0 = r0 > K ? 1 : 0, up1 = r1 > K ? 1 : 0;
+        const int child = up0 | (up1 << 1) | (up2 << 2);
+        const int loc = (r0 - K * up0) + N1 * (r1 - K * up1) + (DIM == 3 ? N1 * N1 * (r2 - K * up2) : 0);
+        const uint32_t fn = A.cnfT[(size_t)loc * A.cstride_f + ch[child]] & NODE_MASK;
+        v[r1][r0] = A.inv_mult[fn] * A.src[(size_t)fn * NC + c];
       }
-    }
+    double tx[NF][N1];
+#pragma unroll
+    for (int r1 = 0; r1 < NF; ++r1)
+#pragma unroll
+      for (int i0 = 0; i0 < N1; ++i0) {
+        double s = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < NF; ++r0)
+          if (pw<K>(r0, i0) != 0.0) s = fma(pw<K>(r0, i0), v[r1][r0], s);
+        tx[r1][i0] = s;
+      }
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+      for (int i0 = 0; i0 < N1; ++i0) {
+        double s = 0.0;
+#pragma unroll
+        for (int r1 = 0; r1 < NF; ++r1)
+          if (pw<K>(r1, i1) != 0.0) s = fma(pw<K>(r1, i1), tx[r1][i0], s);
+#pragma unroll
+        for (int i2 = 0; i2 < NZC; ++i2) {
+          const double w = (DIM == 3) ? pw<K>(r2, i2) : 1.0;
+          if (w != 0.0) acc[i0 + N1 * (i1 + N1 * i2)] = fma(w, s, acc[i0 + N1 * (i1 + N1 * i2)]);
+        }
+      }
   }
-  for (int c = 0; c < NC; ++c) A.slots[((size_t)a * A.cstride_c + cell) * NC + c] = acc[c];
+#pragma unroll
+  for (int a = 0; a < NLOC; ++a) A.slots[((size_t)a * A.cstride_c + cell) * NC + c] = acc[a];
 }
 
 }  // namespace
@@ -167,9 +191,7 @@ int launch_restrict_cells(hipStream_t s, const DeviceLevel &fine, const DeviceLe
   a.inv_mult = velocity ? fine.inv_mult_v : fine.inv_mult_p;
   a.src = src_fine;
   a.slots = slots;
-  const int k1 = velocity ? 3 : 2;
-  const int nloc = fine.dim == 3 ? k1 * k1 * k1 : k1 * k1;
-  const long n = (long)coarse.n_cells * nloc;
+  const long n = (long)coarse.n_cells * (velocity ? fine.dim : 1);
   if (n <= 0) return 0;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (fine.dim == 3) {
