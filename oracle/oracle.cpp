@@ -41,6 +41,7 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+#include <map>
 #endif
 
 namespace {
@@ -336,6 +337,31 @@ void cell_apply_mass(const Level &L, const CellData &cd, int cell, const double 
   q1_values_T<DIM>(pq, pout);
 }
 
+// Threads of the CPU baseline leg of bench.py (ORACLE_THREADS, default 1 = the serial loop the
+// tests use).  Threaded cell loops run colour by colour: cells of one colour share no node, so
+// there are no races and the sums do not depend on the thread count.
+static int oracle_threads() {
+  static const int n = [] { const char *e = getenv("ORACLE_THREADS"); return e ? std::max(1, atoi(e)) : 1; }();
+  return n;
+}
+static const std::vector<std::vector<int>> &cell_colours(const Level &L) {
+  static std::map<const Level *, std::vector<std::vector<int>>> cache;
+  auto it = cache.find(&L);
+  if (it != cache.end() && !it->second.empty()) return it->second;
+  std::vector<std::vector<int>> &col = cache[&L];
+  std::vector<uint64_t> used(L.n_nodes_v, 0);
+  for (int cell = 0; cell < L.n_cells; ++cell) {
+    uint64_t forbidden = 0;
+    for (int i = 0; i < L.nv; ++i) forbidden |= used[L.cnv[size_t(cell) * L.nv + i]];
+    int k = 0;
+    while (k < 63 && ((forbidden >> k) & 1)) ++k;
+    for (int i = 0; i < L.nv; ++i) used[L.cnv[size_t(cell) * L.nv + i]] |= uint64_t(1) << k;
+    if ((int)col.size() <= k) col.resize(k + 1);
+    col[k].push_back(cell);
+  }
+  return col;
+}
+
 // dst = Op src with MatrixFreeOperators::Base::vmult semantics.
 // su/sp, du/dp: velocity and pressure parts (may be null when unused).
 template <int DIM>
@@ -344,7 +370,16 @@ void op_vmult(const Level &L, const CellData &cd, Mode mode,
   const int NV = L.nv, NP = L.np;
   std::fill(du, du + L.ndv(), 0.0);
   if (dp) std::fill(dp, dp + L.ndp(), 0.0);
-  for (int cell = 0; cell < L.n_cells; ++cell) {
+  const int nthreads = oracle_threads();
+  const bool threaded = nthreads > 1 && L.n_cells >= 512;
+  std::vector<std::vector<int>> serial_one;
+  if (!threaded) { serial_one.resize(1); }
+  const std::vector<std::vector<int>> &colours = threaded ? cell_colours(L) : serial_one;
+  for (size_t colour = 0; colour < colours.size(); ++colour) {
+  const int n_in_colour = threaded ? (int)colours[colour].size() : L.n_cells;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (threaded)
+  for (int k = 0; k < n_in_colour; ++k) {
+    const int cell = threaded ? colours[colour][k] : k;
     double uin[3][27], pin[8], uout[3][27], pout[8];
     const uint32_t *nv = &L.cnv[size_t(cell) * NV];
     const uint32_t *np = &L.cnp[size_t(cell) * NP];
@@ -361,6 +396,7 @@ void op_vmult(const Level &L, const CellData &cd, Mode mode,
     if (mode == M_STOKES)
       for (int i = 0; i < NP; ++i)
         if (!L.constrained_p(np[i])) dp[np[i]] += pout[i];
+  }
   }
   // constrained rows are identity
   for (int n = 0; n < L.n_nodes_v; ++n)
