@@ -11,8 +11,12 @@ of uniformly refined levels:
 * cells in hierarchical (Morton) order inside each coarse cell, so the
   children of cell ``P`` on level ``l-1`` are cells ``2^dim*P + c`` on level
   ``l`` (p4est/deal.II child order: bit0 -> x, bit1 -> y, bit2 -> z);
-* Q2 velocity nodes / Q1 pressure nodes numbered lexicographically on the
-  level grid; velocity DoF = ``dim*node + component``;
+* Q2 velocity nodes / Q1 pressure nodes numbered either lexicographically on
+  the level grid or (``numbering="cellwise"``) in the order in which a walk
+  over the cells first meets them -- the locality deal.II's own numbering has
+  (DoFs are distributed cell by cell along the space-filling curve), which
+  keeps the nodes of a run of consecutive cells close together in memory;
+  velocity DoF = ``dim*node + component``;
 * per-node constraint bit masks (bit c: component c is a homogeneous
   Dirichlet row: zero velocity -> all bits, axis-aligned no-normal-flux ->
   the normal component only; local_smoothing.cc:1597-1620, 1675-1698,
@@ -79,8 +83,10 @@ BC_NONE, BC_ZERO, BC_TANGENTIAL = 0, 1, 2
 class Level:
     """Flat tables of one mesh level (what ``agmg_level_desc`` carries)."""
 
-    def __init__(self, dim, extents, reps, l, bc, deform=None, periodic=None):
+    def __init__(self, dim, extents, reps, l, bc, deform=None, periodic=None, numbering="lexicographic"):
         self.dim = dim
+        self.numbering = numbering
+        self.lex_of_v = self.lex_of_p = None   # new node index -> lexicographic index (cellwise only)
         self.deform = deform
         # periodic directions (geometry_model/box.cc "X periodic"): the nodes of the upper face are
         # the nodes of the lower face, i.e. periodicity is plain cell -> node connectivity here
@@ -111,6 +117,11 @@ class Level:
         self.n_nodes_p = int(np.prod(self.npd))
         self.cell_nodes_v = self._cell_nodes(3, 2, self.nvd)
         self.cell_nodes_p = self._cell_nodes(2, 1, self.npd)
+        if numbering == "cellwise":
+            self.cell_nodes_v, self.lex_of_v = self._first_touch(self.cell_nodes_v, self.n_nodes_v)
+            self.cell_nodes_p, self.lex_of_p = self._first_touch(self.cell_nodes_p, self.n_nodes_p)
+        elif numbering != "lexicographic":
+            raise ValueError(f"unknown numbering {numbering!r}")
         self.cmask_v = self._constraint_mask(bc)
         self.cmask_p = np.zeros(self.n_nodes_p, dtype=np.uint8)
         self.cell_h = np.tile(self.h, (self.n_cells, 1))
@@ -135,6 +146,17 @@ class Level:
         self.jxw = det * W[None, :]
 
     # -- tables -----------------------------------------------------------
+    @staticmethod
+    def _first_touch(cell_nodes, n_nodes):
+        """Renumber nodes in the order the cell walk first meets them (cell-local order inside a cell)."""
+        flat = cell_nodes.reshape(-1).astype(np.int64)
+        uniq, first = np.unique(flat, return_index=True)
+        assert uniq.size == n_nodes
+        lex_of = uniq[np.argsort(first, kind="stable")]
+        new_of = np.empty(n_nodes, dtype=np.int64)
+        new_of[lex_of] = np.arange(n_nodes)
+        return new_of[flat].reshape(cell_nodes.shape).astype(np.uint32), lex_of
+
     def _cell_nodes(self, n1, stride, nd):
         dim = self.dim
         loc = np.indices((n1,) * dim).reshape(dim, -1)[::-1]  # x fastest
@@ -149,11 +171,15 @@ class Level:
     def node_coords_v(self):
         idx = np.indices(tuple(self.nvd[::-1])).reshape(self.dim, -1)[::-1]
         x = np.stack([idx[d] * (self.h[d] / 2) for d in range(self.dim)], axis=1)
+        if self.lex_of_v is not None:
+            x = x[self.lex_of_v]
         return self.deform(x) if self.deform is not None else x
 
     def node_coords_p(self):
         idx = np.indices(tuple(self.npd[::-1])).reshape(self.dim, -1)[::-1]
         x = np.stack([idx[d] * self.h[d] for d in range(self.dim)], axis=1)
+        if self.lex_of_p is not None:
+            x = x[self.lex_of_p]
         return self.deform(x) if self.deform is not None else x
 
     def _constraint_mask(self, bc):
@@ -173,7 +199,7 @@ class Level:
                     mask[on] |= allbits
                 elif code == BC_TANGENTIAL:
                     mask[on] |= (1 << d)
-        return mask
+        return mask if self.lex_of_v is None else mask[self.lex_of_v]
 
     def qpoint_coords(self):
         """Physical coordinates of the 3^dim Gauss points, [n_cells][nq][dim]."""
@@ -212,14 +238,14 @@ class BoxHierarchy:
     """Levels 0..refinement of a box; level ``refinement`` is also the active mesh."""
 
     def __init__(self, dim, refinement, extents=None, reps=None, bc=None, only_finest=False, deform=None,
-                 periodic=None):
+                 periodic=None, numbering="lexicographic"):
         self.dim = dim
         extents = [1.0] * dim if extents is None else extents
         reps = [1] * dim if reps is None else reps
         bc = [BC_TANGENTIAL] * (2 * dim) if bc is None else bc
         self.bc = list(bc)
         first = refinement if only_finest else 0
-        self.levels = [Level(dim, extents, reps, l, bc, deform, periodic) for l in range(first, refinement + 1)]
+        self.levels = [Level(dim, extents, reps, l, bc, deform, periodic, numbering) for l in range(first, refinement + 1)]
 
     @property
     def finest(self):

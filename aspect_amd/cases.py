@@ -58,12 +58,13 @@ class StokesProblem:
     initial_pressure: callable = None   # x -> p0 (unscaled), static pressure guess
     deform: callable = None             # x -> x' smooth map of the box (general / MappingQ geometry)
     periodic: list = None               # periodic directions of the box
+    numbering: str = "lexicographic"    # node numbering of the host mesh (boxmesh.Level)
     force_q: callable = None            # level -> rho*g at the q-points [n_cells, nq, dim] (FE-field densities)
     hier: bm.BoxHierarchy = field(default=None, repr=False)
 
     def build(self):
         self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    deform=self.deform, periodic=self.periodic)
+                                    deform=self.deform, periodic=self.periodic, numbering=self.numbering)
         self.eta_active, self.eta_levels, self.eta_min, self.eta_max = \
             bm.viscosity_tables(self.hier, self.eta, self.averaging)
         fin = self.hier.finest
@@ -78,7 +79,7 @@ class StokesProblem:
     def build_single_level(self):
         """Only the active mesh (operator benchmarks on big levels: no hierarchy, no RHS)."""
         self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    only_finest=True, deform=self.deform, periodic=self.periodic)
+                                    only_finest=True, deform=self.deform, periodic=self.periodic, numbering=self.numbering)
         fin = self.hier.finest
         nq = 3 ** self.dim
         if self.averaging == bm.AVG_HARMONIC:

@@ -148,6 +148,7 @@ struct agmg_ctx {
   bool mg_alloc = false, diag_ready = false, smoothers_ready = false;
   double *dot_partials = nullptr, *dot_out_d = nullptr, *dot_out_h = nullptr;
   std::vector<double *> pool;  // Krylov work vectors of size n_u + n_p
+  std::vector<double *> bicg_pool;  // three more velocity vectors for BiCGStab on a non-symmetric A block
   int nA = 0, nS = 0;          // V-cycle / inner iteration counters of the current preconditioner
   std::vector<double> h0, h1;  // host staging for the coarse level
 
@@ -266,6 +267,9 @@ struct agmg_ctx {
   int solver_cg(const std::function<int(double *, const double *)> &A,
                 const std::function<int(double *, const double *)> &P, double *x, const double *b, const Span &sp,
                 int max_it, double tol, double *work[4], int *its, bool *converged);
+  int solver_bicgstab(const std::function<int(double *, const double *)> &A,
+                      const std::function<int(double *, const double *)> &P, double *x, const double *b, const Span &sp,
+                      int max_it, double tol, double *work[7], int *its, bool *converged);
   int bt_residual(double *dst, const double *b, const double *p);
   int restrict_to(int which, int l, const double *src_fine, const EpiArgs &e);
   int prolongate_from(int which, int l, double *dst_fine, const double *src_coarse);
@@ -1061,6 +1065,75 @@ int agmg_ctx::solver_cg(const std::function<int(double *, const double *)> &A,
   return 0;
 }
 
+// deal.II SolverBicgstab, AdditionalData(exact_residual = false), as BlockSchurGMGPreconditioner uses
+// it for a non-symmetric A block (stokes_matrix_free.h:321-333); work = {r, rbar, p, y, z, t, v}
+int agmg_ctx::solver_bicgstab(const std::function<int(double *, const double *)> &A,
+                              const std::function<int(double *, const double *)> &P, double *x, const double *b,
+                              const Span &sp, int max_it, double tol, double *work[7], int *its, bool *converged) {
+  const size_t n = sp.n;
+  double *r = work[0], *rbar = work[1], *p = work[2], *y = work[3], *z = work[4], *t = work[5], *v = work[6];
+  const double breakdown = std::numeric_limits<double>::min();
+  int step = 0;
+  *its = 0;
+  *converged = false;
+  auto status = [&](double res) {
+    *its = step;
+    if (res <= tol) return ST_SUCCESS;
+    if (step >= max_it || !std::isfinite(res)) return ST_FAILURE;
+    return ST_ITERATE;
+  };
+  for (int restart = 0; restart < 1000; ++restart) {
+    CHECK(A(r, x));
+    CHECK(vec_lincomb(stream, r, 1.0, b, -1.0, r, n));
+    double res;
+    CHECK(norm(r, sp, &res));
+    int state = status(res);
+    if (state == ST_SUCCESS) { *converged = true; return 0; }
+    if (state == ST_FAILURE) return 0;
+    double alpha = 1, omega = 1, rho = 1;
+    CHECK(vec_copy(stream, rbar, r, n));
+    bool startup = true, broke = false;
+    do {
+      ++step;
+      double rhobar;
+      CHECK(dots(r, {rbar}, sp, &rhobar));
+      if (std::fabs(rhobar) < breakdown) { broke = true; break; }
+      const double beta = rhobar * alpha / (rho * omega);
+      rho = rhobar;
+      if (startup) { CHECK(vec_copy(stream, p, r, n)); startup = false; }
+      else {
+        CHECK(vec_sadd(stream, p, beta, 1.0, r, n));
+        CHECK(vec_axpy(stream, p, -beta * omega, v, n));
+      }
+      CHECK(P(y, p));
+      CHECK(A(v, y));
+      CHECK(dots(rbar, {v}, sp, &rhobar));
+      if (std::fabs(rhobar) < breakdown) { broke = true; break; }
+      alpha = rho / rhobar;
+      CHECK(vec_axpy(stream, r, -alpha, v, n));
+      CHECK(norm(r, sp, &res));
+      if (status(res) == ST_SUCCESS) {
+        CHECK(vec_axpy(stream, x, alpha, y, n));
+        *converged = true;
+        return 0;
+      }
+      CHECK(P(z, r));
+      CHECK(A(t, z));
+      double d2[2];
+      CHECK(dots(t, {r, t}, sp, d2));
+      if (d2[1] < breakdown) { broke = true; break; }
+      omega = d2[0] / d2[1];
+      CHECK(vec_axpy(stream, x, alpha, y, n));
+      CHECK(vec_axpy(stream, x, omega, z, n));
+      CHECK(vec_axpy(stream, r, -omega, t, n));
+      CHECK(norm(r, sp, &res));
+      state = status(res);
+    } while (state == ST_ITERATE);
+    if (!broke) { *converged = state == ST_SUCCESS; return 0; }
+  }
+  return 0;
+}
+
 // BlockSchurGMGPreconditioner::vmult (stokes_matrix_free.h:237-354) on device block vectors
 int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *status) {
   const DeviceLevel &lv = fin();
@@ -1098,15 +1171,26 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
     double nrm;
     CHECK(norm(utmp, span_of(0, top), &nrm));
     CHECK(vec_set(stream, dst_u, 0.0, nu));
-    double *w[4];
+    double *w[7];
     for (int i = 0; i < 4; ++i) CHECK(get_vec(1 + i, &w[i]));
+    if (!opt.A_block_is_symmetric) {
+      while (bicg_pool.size() < 3) {
+        double *v;
+        CHECK(dalloc(&v, nu));
+        bicg_pool.push_back(v);
+      }
+      for (int i = 0; i < 3; ++i) w[4 + i] = bicg_pool[i];
+    }
     auto Aop = [&](double *d, const double *s) {
       EpiArgs e; e.epi = EPI_STORE; e.dst = d; e.x = s;
       return apply_level(0, top, active_coeff(), s, e);
     };
     auto Pop = [&](double *d, const double *s) { return vcycle(0, d, s); };
     int its; bool conv;
-    CHECK(solver_cg(Aop, Pop, dst_u, utmp, span_of(0, top), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
+    if (opt.A_block_is_symmetric)
+      CHECK(solver_cg(Aop, Pop, dst_u, utmp, span_of(0, top), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
+    else
+      CHECK(solver_bicgstab(Aop, Pop, dst_u, utmp, span_of(0, top), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
     nA += its;
     if (!conv && status) *status = -3;
   } else {
@@ -1458,6 +1542,7 @@ void agmg_destroy(agmg_ctx *c) {
   c->dfree(c->active.etaT); c->dfree(c->active.nw_strain); c->dfree(c->active.nw_dEde); c->dfree(c->active.nw_dEdp);
   c->dfree(c->active.dil_lhs); c->dfree(c->active.dil_de); c->dfree(c->active.dil_dp);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
+  for (auto &p : c->bicg_pool) c->dfree(p);
   for (int w = 0; w < 2; ++w)
     for (auto *v : {&c->mg_def[w], &c->mg_sol[w], &c->mg_tmp[w], &c->mg_t[w]})
       for (auto &p : *v) c->dfree(p);
@@ -1629,6 +1714,8 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   c->mg_alloc = false; c->diag_ready = false; c->smoothers_ready = false;
   for (auto &p : c->pool) c->dfree(p);
   c->pool.clear();
+  for (auto &p : c->bicg_pool) c->dfree(p);
+  c->bicg_pool.clear();
   return 0;
 }
 

@@ -745,6 +745,65 @@ CGResult solver_cg(const LinOp &A, const LinOp &P, Vec &x, const Vec &b, int max
   return R;
 }
 
+enum { ST_SUCCESS = 0, ST_ITERATE = 1, ST_FAILURE = 2 };
+// deal.II SolverBicgstab with AdditionalData(exact_residual = false) as BlockSchurGMGPreconditioner
+// uses it for a non-symmetric A block (stokes_matrix_free.h:321-333): right-preconditioned
+// BiCGStab, the residual norm taken from the recursively updated residual, a check after the
+// first half step; a breakdown (|rho| tiny) restarts from the current iterate.
+CGResult solver_bicgstab(const LinOp &A, const LinOp &P, Vec &x, const Vec &b, int max_it, double tol) {
+  const size_t n = b.size();
+  const double breakdown = std::numeric_limits<double>::min();
+  Vec r(n), rbar(n), p(n), y(n), z(n), t(n), v(n);
+  CGResult R{0, 0.0, false, {}};
+  int step = 0;
+  auto status = [&](double res) {   // SolverControl::check
+    R.its = step; R.res = res;
+    if (res <= tol) return ST_SUCCESS;
+    if (step >= max_it || !std::isfinite(res)) return ST_FAILURE;
+    return ST_ITERATE;
+  };
+  for (int restart = 0; restart < 1000; ++restart) {
+    A(r, x);
+    for (size_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+    double res = norm(r);
+    int state = status(res);
+    if (state == ST_SUCCESS) { R.converged = true; return R; }
+    if (state == ST_FAILURE) return R;
+    double alpha = 1, omega = 1, rho = 1;
+    rbar = r;
+    bool startup = true, broke = false;
+    do {
+      ++step;
+      double rhobar = dot(r, rbar);
+      if (std::fabs(rhobar) < breakdown) { broke = true; break; }
+      const double beta = rhobar * alpha / (rho * omega);
+      rho = rhobar;
+      if (startup) { p = r; startup = false; }
+      else for (size_t i = 0; i < n; ++i) p[i] = beta * p[i] + r[i] - beta * omega * v[i];
+      P(y, p);
+      A(v, y);
+      rhobar = dot(rbar, v);
+      if (std::fabs(rhobar) < breakdown) { broke = true; break; }
+      alpha = rho / rhobar;
+      axpy(r, -alpha, v);
+      res = norm(r);
+      if (status(res) == ST_SUCCESS) { axpy(x, alpha, y); R.converged = true; return R; }
+      P(z, r);
+      A(t, z);
+      rhobar = dot(t, r);
+      const double tt = dot(t, t);
+      if (tt < breakdown) { broke = true; break; }
+      omega = rhobar / tt;
+      for (size_t i = 0; i < n; ++i) x[i] += alpha * y[i] + omega * z[i];
+      axpy(r, -omega, t);
+      res = norm(r);
+      state = status(res);
+    } while (state == ST_ITERATE);
+    if (!broke) { R.converged = state == ST_SUCCESS; return R; }
+  }
+  return R;
+}
+
 // ------------------------------------------------------------------ Chebyshev
 struct Chebyshev {
   LinOp A;
@@ -995,7 +1054,8 @@ struct BlockPrec {
       const double nrm = norm(utmp);
       LinOp A = [&](Vec &d, const Vec &s) { op_vmult<DIM>(L, C.active_cd, M_A, s.data(), nullptr, d.data(), nullptr); };
       LinOp P = [&](Vec &d, const Vec &s) { mgA.vcycle(d, s); };
-      CGResult r = solver_cg(A, P, du, utmp, 1000, nrm * C.opt.A_block_tolerance, false, false);
+      CGResult r = C.opt.A_block_is_symmetric ? solver_cg(A, P, du, utmp, 1000, nrm * C.opt.A_block_tolerance, false, false)
+                                              : solver_bicgstab(A, P, du, utmp, 1000, nrm * C.opt.A_block_tolerance);
       nA += r.its;
       if (!r.converged) status = -3;
     } else { mgA.vcycle(du, utmp); nA += 1; }
@@ -1007,7 +1067,6 @@ struct BlockPrec {
 
 // ------------------------------------------------------------------ Krylov
 struct Control { int max_steps; double tol; int last_step = 0; double last_value = 0; std::vector<double> history; };
-enum { ST_SUCCESS = 0, ST_ITERATE = 1, ST_FAILURE = 2 };
 int check(Control &c, int step, double v) {
   c.last_step = step; c.last_value = v; c.history.push_back(v);
   if (v <= c.tol) return ST_SUCCESS;

@@ -46,6 +46,23 @@ def test_solcx_iterations(case, refinement, kw):
     assert rep.n_expensive_iterations == g["solves"][0]["expensive"] == 0
 
 
+def test_bicgstab_inner_solver_for_nonsymmetric_A_block():
+    """A_block_is_symmetric = 0 (stokes_matrix_free.h:321-333): BiCGStab instead of CG inside the
+    expensive A-block solve.  Parity unpinned (no reference output uses it): the check is that the
+    outer FGMRES converges as with CG and that each BiCGStab step costs two V-cycles."""
+    p = cases.solcx(3, n_cheap=0).build()
+    a = pyoracle.solver(p)
+    b = pyoracle.solver(p, A_block_is_symmetric=0)
+    _, ra, _ = a.solve()
+    xb, rb, _ = b.solve()
+    assert rb.n_cheap_iterations == 0 and rb.final_linear_residual <= rb.solver_tolerance
+    assert abs(rb.n_expensive_iterations - ra.n_expensive_iterations) <= 2
+    assert 0 < rb.n_A_preconditioner_expensive <= ra.n_A_preconditioner_expensive
+    rhs = np.concatenate([p.rhs_u, p.rhs_p])
+    assert np.linalg.norm(rhs - b.vmult(capi.OP_STOKES, xb)) <= 1.05 * rb.solver_tolerance
+    a.close(); b.close()
+
+
 def test_no_cheap_expensive_path():
     g = G["no_cheap_gmg"]
     p, rep, rc = solve(cases.solcx(4, n_cheap=0))

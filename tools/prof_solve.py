@@ -10,7 +10,9 @@ from aspect_amd import capi, cases  # noqa: E402
 
 r = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 kind = sys.argv[2] if len(sys.argv) > 2 else "box"
-p = (cases.convection_box(3, r) if kind == "box" else cases.nsinker_box(r)).build()
+p = cases.convection_box(3, r) if kind == "box" else cases.nsinker_box(r)
+p.numbering = os.environ.get("AGMG_NUMBERING", p.numbering)
+p.build()
 opts = {}
 if len(sys.argv) > 3:
     opts["coarse_on_host"] = int(sys.argv[3])

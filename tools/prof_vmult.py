@@ -14,6 +14,7 @@ if kind == "box":
     p = cases.convection_box(3, r)       # per-q viscosity tables
 else:
     p = cases.nsinker_box(r)             # cell-constant (harmonic) viscosity
+p.numbering = os.environ.get("AGMG_NUMBERING", p.numbering)
 p.build_single_level()
 s = capi.Solver(capi.load(), p, single_level=True)
 ops = ((capi.OP_A, "A"), (capi.OP_STOKES, "Stokes"), (capi.OP_MASS, "mass"))
