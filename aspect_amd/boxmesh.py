@@ -213,6 +213,64 @@ class Level:
             out[:, :, d] = (self.cell_ijk[:, d:d + 1] + GAUSS3_X[q[d]][None, :]) * self.h[d]
         return out
 
+    def boundary_faces(self, boundary_id):
+        """Cells with a face on box boundary ``boundary_id`` (deal.II order 2*d + side) -> (cells, face numbers)."""
+        d, side = boundary_id // 2, boundary_id % 2
+        if self.periodic[d]:
+            return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)
+        on = self.cell_ijk[:, d] == (self.ncd[d] - 1 if side else 0)
+        cells = np.nonzero(on)[0].astype(np.uint32)
+        return cells, np.full(cells.size, boundary_id, dtype=np.uint8)
+
+    def face_local_nodes(self, face_number):
+        """Cell-local indices of the 3^(dim-1) Q2 nodes of a face, lexicographic over the tangential directions."""
+        d, side = face_number // 2, face_number % 2
+        loc = np.indices((3,) * self.dim).reshape(self.dim, -1)[::-1]     # x fastest
+        return np.nonzero(loc[d] == (2 if side else 0))[0]
+
+    def face_geometry(self, cells, face_numbers):
+        """Face q-point coordinates, outward unit normals and JxW of the listed faces (Gauss-3 per tangential
+        direction, lexicographic): what FEFaceEvaluation / FEFaceValues hold for them.
+        -> x [faces][nqf][dim], normal [faces][nqf][dim], jxw [faces][nqf]"""
+        dim = self.dim
+        nqf = 3 ** (dim - 1)
+        nf = len(cells)
+        x = np.zeros((nf, nqf, dim)); normal = np.zeros((nf, nqf, dim)); jxw = np.zeros((nf, nqf))
+        X = self.node_coords_v()
+        qt = np.indices((3,) * (dim - 1)).reshape(dim - 1, -1)[::-1]      # tangential q indices, lower direction fastest
+        W = np.prod(GAUSS3_W[qt], axis=0)
+        for fno in np.unique(face_numbers):
+            sel = np.nonzero(face_numbers == fno)[0]
+            d, side = int(fno) // 2, int(fno) % 2
+            tang = [k for k in range(dim) if k != d]
+            # reference coordinates of the face q-points inside the cell
+            xi = np.zeros((nqf, dim))
+            xi[:, d] = float(side)
+            for t, k in enumerate(tang):
+                xi[:, k] = GAUSS3_X[qt[t]]
+            shp = [q2_shape(xi[:, k]) for k in range(dim)]              # [q][i] per direction
+            dshp = [q2_dshape(xi[:, k]) for k in range(dim)]
+            loc = np.indices((3,) * dim).reshape(dim, -1)[::-1]
+            N = np.ones((nqf, 3 ** dim))
+            for k in range(dim):
+                N *= shp[k][:, loc[k]]
+            Xc = X[self.cell_nodes_v[cells[sel]].astype(np.int64)]       # [face][i][dim]
+            x[sel] = np.einsum("qi,fid->fqd", N, Xc)
+            J = np.zeros((sel.size, nqf, dim, dim))                      # d x_d / d xi_e
+            for e in range(dim):
+                dN = np.ones((nqf, 3 ** dim))
+                for k in range(dim):
+                    dN *= (dshp[k] if k == e else shp[k])[:, loc[k]]
+                J[:, :, :, e] = np.einsum("qi,fid->fqd", dN, Xc)
+            # n dS = det(J) J^-T n_ref dxi_tangential
+            det = np.linalg.det(J)
+            nref = np.zeros(dim); nref[d] = 1.0 if side else -1.0
+            v = det[..., None] * np.einsum("fqed,e->fqd", np.linalg.inv(J), nref)
+            area = np.linalg.norm(v, axis=-1)
+            normal[sel] = v / area[..., None]
+            jxw[sel] = area * W[None, :]
+        return x, normal, jxw
+
     def nodal_to_qpoints(self, nodal):
         """Q2 field given at the velocity nodes -> values at the Gauss points, [n_cells][nq]."""
         return nodal[self.cell_nodes_v.astype(np.int64)] @ tensor_shape([N2] * self.dim).T

@@ -70,6 +70,13 @@ class CellData(C.Structure):
     ]
 
 
+class FaceData(C.Structure):
+    _fields_ = [
+        ("n_faces", C.c_int32), ("face_cell", c_u32p), ("face_number", c_u8p),
+        ("stabilization_term", c_dp), ("normal", c_dp), ("jxw", c_dp),
+    ]
+
+
 class SolveReport(C.Structure):
     _fields_ = [
         ("n_cheap_iterations", C.c_int32), ("n_expensive_iterations", C.c_int32),
@@ -85,6 +92,7 @@ class SolveReport(C.Structure):
 SYMBOLS = [
     "default_options", "last_error", "create", "destroy", "set_communicator",
     "rccl_get_unique_id", "set_communicator_rccl", "set_level", "set_coefficients",
+    "set_free_surface_faces",
     "compute_diagonals", "vmult", "vmult_device", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
     "solve", "bench_vmult", "get_cell_data_memory_consumption",
@@ -133,6 +141,7 @@ class Library:
         self.set_communicator_rccl = fn("set_communicator_rccl", C.c_int, [vp, C.POINTER(C.c_uint8)])
         self.set_level = fn("set_level", C.c_int, [vp, C.c_int, C.POINTER(LevelDesc)])
         self.set_coefficients = fn("set_coefficients", C.c_int, [vp, C.c_int, C.POINTER(CellData)])
+        self.set_free_surface_faces = fn("set_free_surface_faces", C.c_int, [vp, C.POINTER(FaceData)])
         self.compute_diagonals = fn("compute_diagonals", C.c_int, [vp])
         self.vmult = fn("vmult", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         self.vmult_device = fn("vmult_device", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
@@ -216,6 +225,8 @@ class Solver:
         for l, lev in enumerate(hier.levels):
             self._set_coeff(l, problem.eta_levels[l])
         self._set_coeff(ACTIVE, problem.eta_active)
+        if getattr(problem, "free_surface", None) is not None:
+            self.set_free_surface_faces(*problem.free_surface)
         if not single_level:
             self._check(lib.compute_diagonals(self.ctx))
         fin = hier.finest
@@ -297,6 +308,25 @@ class Solver:
         cd.n_q_viscosity = t.shape[1]
         cd.viscosity = _ptr(t, C.c_double)
         self._check(self.lib.set_coefficients(self.ctx, l, C.byref(cd)))
+
+    def set_free_surface_faces(self, face_cell=None, face_number=None, stabilization_term=None, normal=None, jxw=None):
+        """Free-surface stabilisation faces of the active Stokes operator (no arguments: remove them)."""
+        if face_cell is None:
+            return self._check(self.lib.set_free_surface_faces(self.ctx, None))
+        fd = FaceData()
+        fc = np.ascontiguousarray(face_cell, dtype=np.uint32)
+        fn = np.ascontiguousarray(face_number, dtype=np.uint8)
+        st = np.ascontiguousarray(stabilization_term, dtype=np.float64)
+        nqf = 3 ** (self.problem.hier.dim - 1)
+        assert fn.size == fc.size and st.shape == (fc.size, nqf, self.problem.hier.dim)
+        fd.n_faces = fc.size
+        fd.face_cell, fd.face_number, fd.stabilization_term = _ptr(fc, C.c_uint32), _ptr(fn, C.c_uint8), _ptr(st, C.c_double)
+        if normal is not None:
+            nr = np.ascontiguousarray(normal, dtype=np.float64)
+            jw = np.ascontiguousarray(jxw, dtype=np.float64)
+            assert nr.shape == st.shape and jw.shape == (fc.size, nqf)
+            fd.normal, fd.jxw = _ptr(nr, C.c_double), _ptr(jw, C.c_double)
+        self._check(self.lib.set_free_surface_faces(self.ctx, C.byref(fd)))
 
     # -- operator interface ---------------------------------------------
     def size(self, which, level=ACTIVE):

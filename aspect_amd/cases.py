@@ -60,6 +60,10 @@ class StokesProblem:
     periodic: list = None               # periodic directions of the box
     numbering: str = "lexicographic"    # node numbering of the host mesh (boxmesh.Level)
     force_q: callable = None            # level -> rho*g at the q-points [n_cells, nq, dim] (FE-field densities)
+    # free-surface stabilisation (mesh deformation with free-surface boundary indicators): dict with
+    # boundaries (box boundary ids), density x -> rho, gravity x -> g vector, dt, theta
+    free_surface_spec: dict = None
+    free_surface: tuple = field(default=None, repr=False)
     hier: bm.BoxHierarchy = field(default=None, repr=False)
 
     def build(self):
@@ -74,7 +78,29 @@ class StokesProblem:
             self.p0 = self.initial_pressure(fin.node_coords_p()) / self.pressure_scaling
         else:
             self.p0 = np.zeros(fin.n_dofs_p)
+        self._free_surface_tables(fin)
         return self
+
+    def _free_surface_tables(self, fin):
+        """free_surface_stabilization_term_table = rho * dt * theta * |g| * g_hat at the face q-points of
+        the faces carrying a free-surface indicator (local_smoothing.cc:665-756)."""
+        spec = self.free_surface_spec
+        if spec is None:
+            return
+        parts = [fin.boundary_faces(b) for b in spec["boundaries"]]
+        cells = np.concatenate([p[0] for p in parts])
+        fnos = np.concatenate([p[1] for p in parts])
+        x, normal, jxw = fin.face_geometry(cells, fnos)
+        xf = x.reshape(-1, self.dim)
+        g = spec["gravity"](xf)
+        gn = np.linalg.norm(g, axis=1)
+        ghat = np.where(gn[:, None] == 0.0, 0.0, g / np.where(gn == 0.0, 1.0, gn)[:, None])
+        pert = spec["density"](xf) * spec["dt"] * spec["theta"] * gn
+        stab = (pert[:, None] * ghat).reshape(x.shape)
+        if fin.general:
+            self.free_surface = (cells, fnos, stab, normal, jxw)
+        else:
+            self.free_surface = (cells, fnos, stab, None, None)
 
     def build_single_level(self):
         """Only the active mesh (operator benchmarks on big levels: no hierarchy, no RHS)."""
@@ -89,6 +115,7 @@ class StokesProblem:
             self.eta_active = self.eta(fin.qpoint_coords().reshape(-1, self.dim)).reshape(fin.n_cells, nq)
         self.eta_levels = [self.eta_active]
         self.eta_min, self.eta_max = float(self.eta_active.min()), float(self.eta_active.max())
+        self._free_surface_tables(fin)
         return self
 
 
@@ -144,6 +171,36 @@ def convection_box(dim, refinement):
         bc=[bm.BC_TANGENTIAL] * (2 * dim), eta=lambda x: np.ones(x.shape[0]),
         force=force, averaging=bm.AVG_PROJECT_Q1, pressure_scaling=100.0,
         initial_pressure=p_static)
+
+
+def free_surface_blob(dim, refinement, dt_theta=0.5, deform=None, side_surface=False):
+    """A dense blob under a free surface (the setting of tests/free_surface_blob_gmg.prm, whose time
+    stepping cannot run here): box with free slip on the sides and bottom, a free top boundary that
+    carries the stabilisation term; ``side_surface`` also frees the x+ side (faces of two directions
+    meeting in an edge)."""
+    g0 = 10.0
+
+    def rho(x):
+        r2 = np.sum((x - 0.5) ** 2, axis=1)
+        return 1.0 + 0.5 * np.exp(-r2 / 0.02)
+
+    def gravity(x):
+        g = np.zeros_like(x)
+        g[:, -1] = -g0
+        return g
+
+    def force(x):
+        return rho(x)[:, None] * gravity(x)
+
+    bc = [bm.BC_TANGENTIAL] * (2 * dim)
+    free = [2 * dim - 1] + ([1] if side_surface else [])
+    for b in free:
+        bc[b] = bm.BC_NONE
+    return StokesProblem(
+        name=f"free_surface_blob_{dim}d_r{refinement}", dim=dim, refinement=refinement, bc=bc,
+        eta=lambda x: np.exp(2.0 * x[:, 0] + np.sin(3.0 * x[:, -1] + x[:, 0])), force=force, averaging=bm.AVG_HARMONIC, pressure_scaling=1.0,
+        initial_pressure=lambda x: g0 * (1.0 - x[:, -1]), deform=deform, tol=1e-7, n_cheap=200, n_expensive=0,
+        free_surface_spec=dict(boundaries=free, density=rho, gravity=gravity, dt=dt_theta, theta=1.0))
 
 
 def solcx(refinement, averaging=bm.AVG_HARMONIC, jump=1e6, n_cheap=1000):

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <map>
 #include <memory>
 #include <random>
 
@@ -139,6 +140,11 @@ struct agmg_ctx {
   std::vector<DeviceLevel> L;
   std::vector<HostLevel> H;
   CoeffData active;
+  FaceTerm faces;   // free-surface stabilisation faces of the active Stokes operator
+  void free_faces() {
+    dfree(faces.nodes); dfree(faces.ptr); dfree(faces.ent); dfree(faces.fnode); dfree(faces.stab); dfree(faces.njxw);
+    faces = FaceTerm();
+  }
   double *slots_u = nullptr, *slots_p = nullptr;
   size_t slots_u_cap = 0, slots_p_cap = 0;
   // multigrid work vectors, [0] = A block (velocity), [1] = Schur complement (pressure)
@@ -688,8 +694,11 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
   eu.dst = dst; eu.x = src;
   ep.dst = dst + nu; ep.x = src + nu;
   if (eu_in.b) ep.b = eu_in.b + nu;
-  if (!dist())
-    return launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_ALL, &ep);
+  if (!dist()) {
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_ALL, &ep));
+    // boundary-face loop of StokesOperator::apply_add (matrix_free_operators.cc:343-353)
+    return launch_face_term(stream, lv.dim, faces, lv.cmask_v, src, dst, eu_in.epi == EPI_RESID ? -1.0 : 1.0);
+  }
   std::vector<Msg> m;
   CHECK(add_update(m, lv.xv, const_cast<double *>(src), lv.xv.nc));
   CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
@@ -1543,6 +1552,7 @@ void agmg_destroy(agmg_ctx *c) {
   c->dfree(c->active.dil_lhs); c->dfree(c->active.dil_de); c->dfree(c->active.dil_dp);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
   for (auto &p : c->bicg_pool) c->dfree(p);
+  c->free_faces();
   for (int w = 0; w < 2; ++w)
     for (auto *v : {&c->mg_def[w], &c->mg_sol[w], &c->mg_tmp[w], &c->mg_t[w]})
       for (auto &p : *v) c->dfree(p);
@@ -1591,6 +1601,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   }
   DeviceLevel &lv = c->L[level];
   c->free_level(lv);
+  if (level == c->nl() - 1) c->free_faces();   // face tables refer to the cells of the active mesh
   HostLevel &hl = c->H[level];
   lv.dim = dim;
   lv.n_cells = d->n_cells; lv.n_nodes_v = d->n_nodes_v; lv.n_nodes_p = d->n_nodes_p;
@@ -1800,6 +1811,79 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   return 0;
 }
 
+int agmg_set_free_surface_faces(agmg_ctx *c, const agmg_face_data *d) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  CHECK(c->sync());
+  c->free_faces();
+  if (!d || d->n_faces == 0) return 0;
+  if (c->dist()) { set_error("free-surface faces are not available in a distributed context yet"); return -2; }
+  if (d->n_faces < 0 || !d->face_cell || !d->face_number || !d->stabilization_term) { set_error("free-surface face tables missing"); return -1; }
+  if ((d->normal == nullptr) != (d->jxw == nullptr)) { set_error("face normal and jxw come together"); return -1; }
+  if (c->L.empty() || !c->fin().set) { set_error("set_free_surface_faces before set_level"); return -1; }
+  const DeviceLevel &lv = c->fin();
+  const HostLevel &hl = c->H[c->nl() - 1];
+  const int dim = lv.dim, NV = ipow(3, dim), NF = ipow(3, dim - 1), NQF = NF, nf = d->n_faces;
+  if (!d->normal && !lv.cell_hT) { set_error("general geometry needs face normals and JxW"); return -1; }
+  if ((uint64_t)nf >= (1ull << 28)) { set_error("too many free-surface faces"); return -1; }
+  for (int f = 0; f < nf; ++f)
+    if ((int)d->face_cell[f] >= lv.n_cells || d->face_number[f] >= 2 * dim) { set_error("free-surface face table out of range"); return -1; }
+  std::vector<double> hT;
+  if (!d->normal) {
+    hT.resize((size_t)dim * lv.cstride);
+    AGMG_HIP_CHECK(hipMemcpy(hT.data(), lv.cell_hT, hT.size() * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  const double wq[3] = {5. / 18., 8. / 18., 5. / 18.};
+  std::vector<uint32_t> fnode((size_t)nf * NF);
+  std::vector<double> stab(d->stabilization_term, d->stabilization_term + (size_t)nf * NQF * dim), njxw((size_t)nf * NQF * dim);
+  std::map<uint32_t, std::vector<uint32_t>> by_node;   // node -> (face << 4 | a), faces ascending
+  for (int f = 0; f < nf; ++f) {
+    const int cell = d->face_cell[f], dir = d->face_number[f] / 2, side = d->face_number[f] % 2;
+    for (int a = 0; a < NF; ++a) {
+      int idx = 0, stride = 1, rem = a;
+      for (int k = 0; k < dim; ++k) {
+        int coord;
+        if (k == dir) coord = side ? 2 : 0;
+        else { coord = rem % 3; rem /= 3; }
+        idx += coord * stride;
+        stride *= 3;
+      }
+      const uint32_t node = hl.cnv[(size_t)cell * NV + idx];
+      fnode[(size_t)f * NF + a] = node;
+      by_node[node].push_back(((uint32_t)f << 4) | (uint32_t)a);
+    }
+    for (int q = 0; q < NQF; ++q) {
+      double n[3] = {0, 0, 0}, jxw;
+      if (d->normal) {
+        for (int cc = 0; cc < dim; ++cc) n[cc] = d->normal[((size_t)f * NQF + q) * dim + cc];
+        jxw = d->jxw[(size_t)f * NQF + q];
+      } else {
+        n[dir] = side ? 1.0 : -1.0;
+        jxw = 1.0;
+        int qq = q;
+        for (int k = 0; k < dim; ++k) {
+          if (k == dir) continue;
+          jxw *= wq[qq % 3] * hT[(size_t)k * lv.cstride + cell];
+          qq /= 3;
+        }
+      }
+      for (int cc = 0; cc < dim; ++cc) njxw[((size_t)f * NQF + q) * dim + cc] = n[cc] * jxw;
+    }
+  }
+  std::vector<uint32_t> nodes, ptr(1, 0), ent;
+  for (auto &kv : by_node) {
+    nodes.push_back(kv.first);
+    ent.insert(ent.end(), kv.second.begin(), kv.second.end());
+    ptr.push_back((uint32_t)ent.size());
+  }
+  FaceTerm &F = c->faces;
+  CHECK(c->upload(&F.nodes, nodes)); CHECK(c->upload(&F.ptr, ptr)); CHECK(c->upload(&F.ent, ent));
+  CHECK(c->upload(&F.fnode, fnode)); CHECK(c->upload(&F.stab, stab)); CHECK(c->upload(&F.njxw, njxw));
+  F.n_faces = nf;
+  F.n_nodes = (int)nodes.size();
+  return 0;
+}
+
 int agmg_compute_diagonals(agmg_ctx *c) {
   if (!c) { set_error("null context"); return -1; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
@@ -1863,6 +1947,7 @@ int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const doub
         if (l != c->nl() - 1 || &cd != &c->active_coeff()) { set_error("distributed Stokes vmult: active mesh only"); return -2; }
         return c->stokes_vmult(dst, src);
       }
+      if (level == AGMG_ACTIVE) return c->stokes_vmult(dst, src);   // with the active operator's face terms
       EpiArgs ep = e;
       ep.dst = dst + nu; ep.x = src + nu;
       return launch_op(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p, e, c->use_blocks, PH_ALL, &ep);

@@ -170,6 +170,21 @@ int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, cons
 // Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.
 // Stokes pressure rows are left in slots_p for launch_pull_p(..., dim, ...), or finished here with
 // epilogue *ep (one rank: the velocity fix-up and the pressure pull share one launch).
+// free-surface stabilisation faces of the active Stokes operator (matrix_free_operators.cc:294-333),
+// organised by node: every surface node lists the (face, local index) pairs that touch it
+struct FaceTerm {
+  int n_faces = 0, n_nodes = 0;
+  uint32_t *nodes = nullptr;   // [n_nodes] surface nodes
+  uint32_t *ptr = nullptr;     // [n_nodes + 1] into ent
+  uint32_t *ent = nullptr;     // face << 4 | face-local node index
+  uint32_t *fnode = nullptr;   // [n_faces][3^(dim-1)] nodes of each face
+  double *stab = nullptr;      // [n_faces][nqf][dim] pressure_perturbation * g_hat
+  double *njxw = nullptr;      // [n_faces][nqf][dim] outward normal * JxW
+};
+// dst_u += sign * (face term applied to src_u), unconstrained rows only
+int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *src_u,
+                     double *dst_u, double sign);
+
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,
               int phase = PH_ALL, const EpiArgs *ep = nullptr);

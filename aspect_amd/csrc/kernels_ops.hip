@@ -1176,6 +1176,62 @@ __global__ void __launch_bounds__(256) k_fix_pull(const FixArgs F, const PullArg
   else pull_body<1, DIM>(P, blockIdx.x - n_fix_blocks);
 }
 
+// StokesOperator::local_apply_boundary_face (matrix_free_operators.cc:294-333), node-owner form: one
+// thread per surface node sums, face by face in table order, phi_a(q) * (-(g_q . u_q)) * n_q JxW_q
+// over the face q-points.  u_q is recomputed by every node of the face (9 x on a 2-D manifold:
+// negligible next to the cell loop) so that no scatter, no atomics and no second pass are needed.
+template <int DIM>
+__global__ void __launch_bounds__(128) k_face_term(const FaceTerm F, const uint8_t *__restrict__ cmask,
+                                                   const double *__restrict__ src, double *__restrict__ dst,
+                                                   const double sign) {
+  constexpr int NF = DIM == 3 ? 9 : 3, NQF = NF;
+  const int s = blockIdx.x * 128 + threadIdx.x;
+  if (s >= F.n_nodes) return;
+  const double sq = 0.7745966692414834;  // sqrt(3/5)
+  double N2[3][3];                       // [q][i] Q2 values at the Gauss points of the unit interval
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double x = 0.5 + 0.5 * sq * (q - 1);
+    N2[q][0] = (1 - x) * (1 - 2 * x); N2[q][1] = 4 * x * (1 - x); N2[q][2] = x * (2 * x - 1);
+  }
+  const uint32_t node = F.nodes[s];
+  double val[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) val[c] = 0.0;
+  for (uint32_t k = F.ptr[s]; k < F.ptr[s + 1]; ++k) {
+    const uint32_t e = F.ent[k], f = e >> 4, a = e & 15u;
+    double u[NF][DIM];
+#pragma unroll
+    for (int b = 0; b < NF; ++b) {
+      const uint32_t nb = F.fnode[(size_t)f * NF + b];
+      const uint8_t m = cmask[nb];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) u[b][c] = ((m >> c) & 1) ? 0.0 : src[(size_t)nb * DIM + c];
+    }
+#pragma unroll
+    for (int q = 0; q < NQF; ++q) {
+      const double *g = F.stab + ((size_t)f * NQF + q) * DIM;
+      const double *nj = F.njxw + ((size_t)f * NQF + q) * DIM;
+      double gu = 0.0, pa = 0.0;
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        const double pb = DIM == 3 ? N2[q % 3][b % 3] * N2[q / 3][b / 3] : N2[q][b];
+        if ((uint32_t)b == a) pa = pb;
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) t = fma(g[c], u[b][c], t);
+        gu = fma(pb, t, gu);
+      }
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) val[c] = fma(-pa * gu, nj[c], val[c]);
+    }
+  }
+  const uint8_t m = cmask[node];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c)
+    if (!((m >> c) & 1)) dst[(size_t)node * DIM + c] += sign * val[c];
+}
+
 CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
                    double *slp) {
   CellArgs a;
@@ -1264,6 +1320,17 @@ int launch_blk_op(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiA
 }
 
 }  // namespace
+
+int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *src_u,
+                     double *dst_u, double sign) {
+  if (ft.n_nodes <= 0) return 0;
+  const dim3 grid((ft.n_nodes + 127) / 128), block(128);
+  if (dim == 3) hipLaunchKernelGGL((k_face_term<3>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign);
+  else hipLaunchKernelGGL((k_face_term<2>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign);
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 
 int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
                     const double *src_p, double *slots_u, double *slots_p) {

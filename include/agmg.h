@@ -171,6 +171,24 @@ typedef struct agmg_cell_data {
   const double *dilation_derivative_wrt_pressure;        /* [n_cells][nq] */
 } agmg_cell_data;
 
+/* Free-surface stabilisation faces of the active Stokes operator: the
+ * apply_stabilization_free_surface_faces branch of OperatorCellData
+ * (matrix_free_operators.h:91-203) with its free_surface_stabilization_term_table
+ * (filled in local_smoothing.cc:665-756: pressure_perturbation * g_hat per face
+ * q-point) and free_surface_boundary_indicators: the caller lists the boundary
+ * faces that carry such an indicator.  Face q-points and face nodes are ordered
+ * lexicographically over the tangential directions (lower direction fastest),
+ * Gauss-3 per direction (face_quadratures.velocities). */
+typedef struct agmg_face_data {
+  int32_t n_faces;                  /* 0 switches the term off */
+  const uint32_t *face_cell;        /* [n_faces] cell of the active mesh */
+  const uint8_t  *face_number;      /* [n_faces] deal.II face number 2*direction + side */
+  const double *stabilization_term; /* [n_faces][3^(dim-1)][dim] */
+  const double *normal;             /* [n_faces][3^(dim-1)][dim] outward unit normals, or NULL
+                                       (Cartesian geometry: +-e_direction) */
+  const double *jxw;                /* [n_faces][3^(dim-1)] face JxW, or NULL with normal == NULL */
+} agmg_face_data;
+
 /* Mirrors the screen/statistics output of solve()
  * (local_smoothing.cc:1421-1425, 1526-1536; SolverOutputs interface.h:36-58). */
 typedef struct agmg_solve_report {
@@ -225,6 +243,14 @@ int agmg_set_level(agmg_ctx *ctx, int level, const agmg_level_desc *desc);
 /* evaluate_material_model() -> OperatorCellData per level
  * (local_smoothing.cc:172-445; set_cell_data matrix_free_operators.cc:151, 381, 511, 698) */
 int agmg_set_coefficients(agmg_ctx *ctx, int level, const agmg_cell_data *data);
+
+/* The boundary-face term of StokesOperator (local_apply_boundary_face,
+ * matrix_free_operators.cc:294-333; apply_add :337-358): dst_u += sum over the
+ * listed faces of integral phi_i . (-(g . u) n).  Active Stokes operator only
+ * (the reference has no multilevel surface terms, local_smoothing.cc:668-670);
+ * data == NULL or n_faces == 0 removes it.  Not available in a distributed
+ * context yet. */
+int agmg_set_free_surface_faces(agmg_ctx *ctx, const agmg_face_data *data);
 
 /* build_preconditioner(): ABlockOperator/MassMatrixOperator::compute_diagonal on
  * every level (local_smoothing.cc:1882-1894; matrix_free_operators.cc:592-639, 799-829) */

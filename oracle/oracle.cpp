@@ -117,6 +117,12 @@ struct CellData {
   Vec strain, dEde, dEdp;
   // prescribed dilation (active level): LHS term [n_cells][nq]; with Newton its derivatives
   Vec dil_lhs, dil_de, dil_dp;
+  // free-surface stabilisation faces (active level; apply_stabilization_free_surface_faces,
+  // free_surface_stabilization_term_table: local_smoothing.cc:665-756)
+  int n_faces = 0;
+  std::vector<uint32_t> face_cell;
+  std::vector<uint8_t> face_no;        // deal.II face number 2*d + side
+  Vec face_stab, face_normal, face_jxw;  // [face][q][dim], [face][q][dim] or empty, [face][q] or empty
 };
 inline int symc(int dim, int a, int b) {
   if (a == b) return a;
@@ -362,6 +368,114 @@ static const std::vector<std::vector<int>> &cell_colours(const Level &L) {
   return col;
 }
 
+// geometry of face q-point q of boundary face f: outward normal and JxW (caller's tables, or
+// +-e_d and the face area weights of a Cartesian cell)
+template <int DIM>
+inline void face_geometry(const Level &L, const CellData &cd, int f, int q, double n[3], double &jxw) {
+  constexpr int NQF = DIM == 3 ? 9 : 3;
+  const int cell = cd.face_cell[f], d = cd.face_no[f] / 2, side = cd.face_no[f] % 2;
+  if (!cd.face_normal.empty()) {
+    for (int c = 0; c < DIM; ++c) n[c] = cd.face_normal[(size_t(f) * NQF + q) * DIM + c];
+    jxw = cd.face_jxw[size_t(f) * NQF + q];
+    return;
+  }
+  for (int c = 0; c < DIM; ++c) n[c] = 0.0;
+  n[d] = side ? 1.0 : -1.0;
+  double w = 1.0;
+  int qq = q;
+  for (int k = 0; k < DIM; ++k) {
+    if (k == d) continue;
+    w *= T.wq[qq % 3] * L.cell_h[size_t(cell) * DIM + k];
+    qq /= 3;
+  }
+  jxw = w;
+}
+// cell-local index of face node a (lexicographic over the tangential directions, lower first)
+template <int DIM>
+inline int face_node_local(int fno, int a) {
+  const int d = fno / 2, side = fno % 2;
+  int idx = 0, stride = 1;
+  for (int k = 0; k < DIM; ++k) {
+    int coord;
+    if (k == d) coord = side ? 2 : 0;
+    else { coord = a % 3; a /= 3; }
+    idx += coord * stride;
+    stride *= 3;
+  }
+  return idx;
+}
+
+// StokesOperator::local_apply_boundary_face (matrix_free_operators.cc:294-333): on every free-surface
+// face evaluate u at the face q-points, submit -(g . u) n, integrate against the velocity values.
+template <int DIM>
+void face_terms(const Level &L, const CellData &cd, const double *su, double *du) {
+  constexpr int NF = DIM == 3 ? 9 : 3, NQF = NF;
+  for (int f = 0; f < cd.n_faces; ++f) {
+    const uint32_t *nv = &L.cnv[size_t(cd.face_cell[f]) * L.nv];
+    int node[NF];
+    double u[NF][DIM], out[NF][DIM];
+    for (int a = 0; a < NF; ++a) {
+      node[a] = nv[face_node_local<DIM>(cd.face_no[f], a)];
+      for (int c = 0; c < DIM; ++c) {
+        u[a][c] = L.constrained_v(node[a], c) ? 0.0 : su[size_t(node[a]) * DIM + c];
+        out[a][c] = 0.0;
+      }
+    }
+    for (int q = 0; q < NQF; ++q) {
+      double shape[NF];
+      for (int a = 0; a < NF; ++a) shape[a] = DIM == 3 ? T.N2[q % 3][a % 3] * T.N2[q / 3][a / 3] : T.N2[q][a];
+      double uq[DIM];
+      for (int c = 0; c < DIM; ++c) {
+        uq[c] = 0.0;
+        for (int a = 0; a < NF; ++a) uq[c] += shape[a] * u[a][c];
+      }
+      double n[3], jxw, gu = 0.0;
+      face_geometry<DIM>(L, cd, f, q, n, jxw);
+      for (int c = 0; c < DIM; ++c) gu += cd.face_stab[(size_t(f) * NQF + q) * DIM + c] * uq[c];
+      for (int a = 0; a < NF; ++a)
+        for (int c = 0; c < DIM; ++c) out[a][c] += shape[a] * (-gu * n[c]) * jxw;
+    }
+    for (int a = 0; a < NF; ++a)
+      for (int c = 0; c < DIM; ++c)
+        if (!L.constrained_v(node[a], c)) du[size_t(node[a]) * DIM + c] += out[a][c];
+  }
+}
+// the same term as a face matrix K[(a,c)][(b,c')] = -sum_q phi_a phi_b n_c g_c' JxW (the bilinear form
+// of assemblers/stokes.cc free-surface stabilisation; second formulation for the oracle's self-check)
+template <int DIM>
+void dense_face_terms(const Level &L, const CellData &cd, const double *su, double *du) {
+  constexpr int NF = DIM == 3 ? 9 : 3, NQF = NF, ND = NF * DIM;
+  for (int f = 0; f < cd.n_faces; ++f) {
+    const uint32_t *nv = &L.cnv[size_t(cd.face_cell[f]) * L.nv];
+    std::vector<double> K(size_t(ND) * ND, 0.0);
+    for (int q = 0; q < NQF; ++q) {
+      double n[3], jxw;
+      face_geometry<DIM>(L, cd, f, q, n, jxw);
+      const double *g = &cd.face_stab[(size_t(f) * NQF + q) * DIM];
+      for (int a = 0; a < NF; ++a)
+        for (int b = 0; b < NF; ++b) {
+          const double pa = DIM == 3 ? T.N2[q % 3][a % 3] * T.N2[q / 3][a / 3] : T.N2[q][a];
+          const double pb = DIM == 3 ? T.N2[q % 3][b % 3] * T.N2[q / 3][b / 3] : T.N2[q][b];
+          for (int c = 0; c < DIM; ++c)
+            for (int c2 = 0; c2 < DIM; ++c2) K[size_t(a * DIM + c) * ND + b * DIM + c2] -= pa * pb * n[c] * g[c2] * jxw;
+        }
+    }
+    for (int a = 0; a < NF; ++a) {
+      const int na = nv[face_node_local<DIM>(cd.face_no[f], a)];
+      for (int c = 0; c < DIM; ++c) {
+        if (L.constrained_v(na, c)) continue;
+        double sum = 0.0;
+        for (int b = 0; b < NF; ++b) {
+          const int nb = nv[face_node_local<DIM>(cd.face_no[f], b)];
+          for (int c2 = 0; c2 < DIM; ++c2)
+            if (!L.constrained_v(nb, c2)) sum += K[size_t(a * DIM + c) * ND + b * DIM + c2] * su[size_t(nb) * DIM + c2];
+        }
+        du[size_t(na) * DIM + c] += sum;
+      }
+    }
+  }
+}
+
 // dst = Op src with MatrixFreeOperators::Base::vmult semantics.
 // su/sp, du/dp: velocity and pressure parts (may be null when unused).
 template <int DIM>
@@ -398,6 +512,7 @@ void op_vmult(const Level &L, const CellData &cd, Mode mode,
         if (!L.constrained_p(np[i])) dp[np[i]] += pout[i];
   }
   }
+  if (mode == M_STOKES && cd.n_faces) face_terms<DIM>(L, cd, su, du);
   // constrained rows are identity
   for (int n = 0; n < L.n_nodes_v; ++n)
     if (L.cmv[n])
@@ -612,6 +727,7 @@ void dense_vmult(const Level &L, const CellData &cd, int which, const double *sr
     if (which == AGMG_OP_STOKES)
       for (int i = 0; i < NP; ++i) dp[np[i]] += y[DIM * NV + i];
   }
+  if (which == AGMG_OP_STOKES && cd.n_faces) dense_face_terms<DIM>(L, cd, su, du);
   if (which != AGMG_OP_MASS)
     for (int n = 0; n < L.n_nodes_v; ++n)
       for (int c = 0; c < DIM; ++c)
@@ -1432,6 +1548,29 @@ int oracle_set_coefficients(oracle_ctx *o, int level, const agmg_cell_data *d) {
   cd->eta.assign(d->viscosity, d->viscosity + size_t(nc) * cd->nqv);
   cd->set = true;
   C.smoothers_ready = false;
+  return 0;
+}
+
+int oracle_set_free_surface_faces(oracle_ctx *o, const agmg_face_data *d) {
+  Ctx &C = o->c;
+  CellData &cd = C.active_cd;
+  const int dim = C.opt.dim, nqf = ipow(3, dim - 1);
+  cd.n_faces = 0;
+  cd.face_cell.clear(); cd.face_no.clear(); cd.face_stab.clear(); cd.face_normal.clear(); cd.face_jxw.clear();
+  if (!d || d->n_faces == 0) return 0;
+  if (!d->face_cell || !d->face_number || !d->stabilization_term) { g_error = "free-surface face tables missing"; return -1; }
+  if ((d->normal == nullptr) != (d->jxw == nullptr)) { g_error = "face normal and jxw come together"; return -1; }
+  if (!d->normal && C.fin().geom != AGMG_GEOM_CARTESIAN) { g_error = "general geometry needs face normals and JxW"; return -1; }
+  for (int f = 0; f < d->n_faces; ++f)
+    if (int(d->face_cell[f]) >= C.fin().n_cells || d->face_number[f] >= 2 * dim) { g_error = "face table out of range"; return -1; }
+  cd.n_faces = d->n_faces;
+  cd.face_cell.assign(d->face_cell, d->face_cell + d->n_faces);
+  cd.face_no.assign(d->face_number, d->face_number + d->n_faces);
+  cd.face_stab.assign(d->stabilization_term, d->stabilization_term + size_t(d->n_faces) * nqf * dim);
+  if (d->normal) {
+    cd.face_normal.assign(d->normal, d->normal + size_t(d->n_faces) * nqf * dim);
+    cd.face_jxw.assign(d->jxw, d->jxw + size_t(d->n_faces) * nqf);
+  }
   return 0;
 }
 

@@ -320,6 +320,47 @@ def test_bicgstab_for_nonsymmetric_A_block(hip_lib, oracle_lib):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("dim,refinement,kw", [
+    (2, 4, {}), (3, 3, {}), (3, 2, {"side_surface": True}),
+    (2, 3, {"deform": lambda x: x + 0.03 * np.sin(2 * x[:, ::-1] + 0.5)}),
+    (3, 2, {"deform": lambda x: x + 0.02 * np.sin(2 * x[:, ::-1] + 0.5)}),
+])
+def test_free_surface_face_term(dim, refinement, kw, hip_lib, oracle_lib):
+    """StokesOperator::local_apply_boundary_face (matrix_free_operators.cc:294-358): operator parity with
+    and without the faces, the residual form used inside solve(), and a whole solve."""
+    p = cases.free_surface_blob(dim, refinement, **kw)
+    g, o = make_pair(p, hip_lib, oracle_lib)
+    fin = p.hier.finest
+    src = rand_vec(g.size(capi.OP_STOKES), 77, fin)
+    a, b = g.vmult(capi.OP_STOKES, src), o.vmult(capi.OP_STOKES, src)
+    assert relerr(a, b) < RTOL
+    g.set_free_surface_faces()
+    o.set_free_surface_faces()
+    a0, b0 = g.vmult(capi.OP_STOKES, src), o.vmult(capi.OP_STOKES, src)
+    assert relerr(a0, b0) < RTOL
+    # the face contribution itself (a difference of O(1e-3) of the operator: looser relative bound)
+    assert np.linalg.norm(b - b0) > 0 and relerr(a - a0, b - b0) < 1e-9
+    # the A block and the level operators carry no face term
+    nu = fin.n_dofs_v
+    assert relerr(g.vmult(capi.OP_A, src[:nu]), o.vmult(capi.OP_A, src[:nu])) < RTOL
+    for s in (g, o):
+        s.set_free_surface_faces(*p.free_surface)
+    xg, rg, _ = g.solve()
+    xo, ro, _ = o.solve()
+    assert abs(rg.n_cheap_iterations - ro.n_cheap_iterations) <= 1
+    assert abs(rg.solver_tolerance - ro.solver_tolerance) <= 1e-10 * ro.solver_tolerance
+    assert rg.final_linear_residual <= rg.solver_tolerance
+    # true residuals: right-preconditioned GMRES only knows its recurrence residual; the rounding of the
+    # preconditioner (1e-12 relative in the Schur V-cycle) puts a floor under the true one for the
+    # oracle and the GPU alike, so the GPU's is measured against the oracle's own
+    rhs = np.concatenate([p.rhs_u, p.rhs_p])
+    res_g = np.linalg.norm(rhs - o.vmult(capi.OP_STOKES, xg))
+    res_o = np.linalg.norm(rhs - o.vmult(capi.OP_STOKES, xo))
+    assert res_g <= max(1.05 * rg.solver_tolerance, 10.0 * res_o)
+    assert relerr(xg[:nu], xo[:nu]) < 1e-4
+    g.close(); o.close()
+
+
 def test_error_paths(hip_lib):
     import ctypes as C
     opt = capi.Options()

@@ -63,6 +63,64 @@ def test_bicgstab_inner_solver_for_nonsymmetric_A_block():
     a.close(); b.close()
 
 
+def _numpy_face_term(p, src_u):
+    """Third, numpy statement of the free-surface face term (matrix_free_operators.cc:294-333) from the
+    host mesh's own face geometry: dst_i += sum_q phi_i(x_q) (-(g_q . u(x_q))) n_q JxW_q."""
+    fin = p.hier.finest
+    dim = p.dim
+    cells, fnos, stab, _, _ = p.free_surface
+    _, normal, jxw = fin.face_geometry(cells, fnos)
+    N1 = bm.q2_shape(bm.GAUSS3_X)                                   # [q][i]
+    N = N1 if dim == 2 else np.kron(N1, N1)                         # face shape table [q][a], lower direction fastest
+    con = fin.constrained_dofs_v().reshape(-1, dim)
+    u = np.where(con, 0.0, src_u.reshape(-1, dim))
+    out = np.zeros_like(u)
+    for f in range(cells.size):
+        nodes = fin.cell_nodes_v[cells[f]][fin.face_local_nodes(int(fnos[f]))].astype(np.int64)
+        uq = N @ u[nodes]                                           # [q][dim]
+        s = -np.sum(stab[f] * uq, axis=1) * jxw[f]                  # [q]
+        out[nodes] += N.T @ (s[:, None] * normal[f])
+    out[con] = 0.0
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("dim,refinement,kw", [
+    (2, 3, {}), (3, 2, {}), (3, 2, {"side_surface": True}),
+    (2, 3, {"deform": lambda x: x + 0.03 * np.sin(2 * x[:, ::-1] + 0.5)}),
+    (3, 2, {"deform": lambda x: x + 0.02 * np.sin(2 * x[:, ::-1] + 0.5)}),
+])
+def test_free_surface_face_term(dim, refinement, kw):
+    """apply_stabilization_free_surface_faces (matrix_free_operators.cc:294-358).  Parity unpinned by the
+    reference (its free-surface GMG tests need the time stepping of the mesh-deformation handler);
+    pinned here by three formulations: evaluate/integrate, face matrices, and numpy on the host mesh's
+    face geometry."""
+    p = cases.free_surface_blob(dim, refinement, **kw).build()
+    s = pyoracle.solver(p)
+    n, nu = s.size(capi.OP_STOKES), p.hier.finest.n_dofs_v
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    with_faces = s.vmult(capi.OP_STOKES, x)
+    dense = s.vmult(capi.OP_STOKES, x, dense=True)
+    s.set_free_surface_faces()
+    without = s.vmult(capi.OP_STOKES, x)
+    face = with_faces - without
+    assert np.linalg.norm(face) > 1e-4 * np.linalg.norm(without)        # the term is not negligible
+    assert np.all(face[nu:] == 0.0)                                     # velocity rows only
+    assert np.linalg.norm(with_faces - dense) <= 1e-13 * np.linalg.norm(dense)
+    ref = _numpy_face_term(p, x[:nu])
+    assert np.linalg.norm(face[:nu] - ref) <= 1e-11 * np.linalg.norm(ref)
+    if not kw.get("deform"):
+        # explicit normals / JxW of a Cartesian mesh = the built-in ones
+        cells, fnos, stab, _, _ = p.free_surface
+        _, normal, jxw = p.hier.finest.face_geometry(cells, fnos)
+        s.set_free_surface_faces(cells, fnos, stab, normal, jxw)
+        again = s.vmult(capi.OP_STOKES, x)
+        assert np.linalg.norm(again - with_faces) <= 1e-13 * np.linalg.norm(with_faces)
+    s.set_free_surface_faces(*p.free_surface)
+    xs, rep, rc = s.solve()
+    assert rc == 0 and rep.final_linear_residual <= rep.solver_tolerance and rep.n_cheap_iterations <= 40
+    s.close()
+
+
 def test_no_cheap_expensive_path():
     g = G["no_cheap_gmg"]
     p, rep, rc = solve(cases.solcx(4, n_cheap=0))
