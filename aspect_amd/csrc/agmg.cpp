@@ -230,6 +230,10 @@ struct agmg_ctx {
   }
 
   bool use_blocks = true;
+  bool use_ell = true;     // assembled rows for the Q1 mass operator (AGMG_NO_ELL=1: matrix-free cell kernel + pull)
+  bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
+    return use_ell && !dist() && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
+  }
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
   // Chebyshev coefficient sequences of cheb_vmult / cheb_step as a program for the fused kernels
   void program_vmult(const Smoother &s, SmootherProgram &p) const;
@@ -294,6 +298,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.gid_v); dfree(l.gid_p);
+  dfree(l.ell_col); dfree(l.coeff.ell_val);
   l = DeviceLevel();
 }
 
@@ -638,6 +643,7 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
   const DeviceLevel &lv = L[l];
   if (!dist()) {
     if (which == 0) return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks);
+    if (mass_ell(lv, cd)) return launch_mass_ell(stream, lv, cd, x, e);
     CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
     return launch_pull_p(stream, lv, slots_p, 1, e);
   }
@@ -1513,6 +1519,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   c->opt = *opt;
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
   c->L.resize(opt->n_levels);
   c->H.resize(opt->n_levels);
   for (int w = 0; w < 2; ++w) c->send_nodes_h[w].resize(opt->n_levels);
@@ -1548,6 +1555,7 @@ void agmg_destroy(agmg_ctx *c) {
   (void)hipSetDevice(c->opt.device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &l : c->L) c->free_level(l);
+  c->dfree(c->active.ell_val);
   c->dfree(c->active.etaT); c->dfree(c->active.nw_strain); c->dfree(c->active.nw_dEde); c->dfree(c->active.nw_dEdp);
   c->dfree(c->active.dil_lhs); c->dfree(c->active.dil_de); c->dfree(c->active.dil_dp);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
@@ -1679,6 +1687,40 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
       for (int i = 0; i < nn; ++i) max_val = std::max(max_val, ptr[i + 1] - ptr[i]);
       lv.mass_fusable = !c->dist() && lv.n_cells <= MS_THREADS && (size_t)lv.n_cells * nloc <= (size_t)MS_MAX_SLOTS &&
                         nn <= MS_MAX_NODES && max_val <= 8;
+      // column structure of the assembled mass rows: the nodes of the cells around each node,
+      // ascending; a patch with more than 3^dim nodes (irregular vertex) keeps the matrix-free path
+      if (!c->dist() && c->use_ell) {
+        const int W = NV;   // 3^dim
+        const size_t npad = ((size_t)nn + 63) / 64 * 64;
+        std::vector<uint32_t> col((size_t)W * npad);
+        bool ok = true;
+        uint32_t nb[64];
+        for (int i = 0; i < nn && ok; ++i) {
+          int cnt = 0;
+          for (uint32_t k = ptr[i]; k < ptr[i + 1] && ok; ++k) {
+            const size_t cell = list[k] % cs;
+            for (int a = 0; a < nloc; ++a) {
+              const uint32_t node = cn[cell * nloc + a];
+              int t = 0;
+              while (t < cnt && nb[t] != node) ++t;
+              if (t == cnt) {
+                if (cnt == W) { ok = false; break; }
+                nb[cnt++] = node;
+              }
+            }
+          }
+          std::sort(nb, nb + cnt);
+          for (int k = 0; k < W; ++k) col[(size_t)k * npad + i] = k < cnt ? nb[k] : (uint32_t)i;
+        }
+        for (size_t i = nn; i < npad; ++i)
+          for (int k = 0; k < W; ++k) col[(size_t)k * npad + i] = 0;
+        if (ok) {
+          CHECK(c->upload(&lv.ell_col, col));
+          lv.ell_w = W;
+          lv.ell_stride = (int)npad;
+          lv.bytes_tables += col.size() * 4;
+        }
+      }
     }
     if (vel) { CHECK(c->upload(&lv.cnvT, T)); CHECK(c->upload(&lv.pull_ptr_v, ptr)); CHECK(c->upload(&lv.pull_list_v, list)); CHECK(c->upload(&lv.cmask_v, cmv)); }
     else { CHECK(c->upload(&lv.cnpT, T)); CHECK(c->upload(&lv.pull_ptr_p, ptr)); CHECK(c->upload(&lv.pull_list_p, list)); CHECK(c->upload(&lv.cmask_p, cmp)); }
@@ -1808,6 +1850,14 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   }
   cd.set = true;
   c->diag_ready = false; c->smoothers_ready = false;
+  // assembled rows of the mass operator with these coefficients (MassMatrixOperator of this level)
+  if (cd.ell_stride != lv.ell_stride) { c->dfree(cd.ell_val); cd.ell_stride = 0; }
+  if (lv.ell_col && c->use_ell && !c->dist()) {
+    if (!cd.ell_val) CHECK(c->dalloc(&cd.ell_val, (size_t)lv.ell_w * lv.ell_stride));
+    cd.ell_stride = lv.ell_stride;
+    CHECK(launch_mass_ell_assemble(c->stream, lv, cd));
+    cd.bytes += (size_t)lv.ell_w * lv.ell_stride * 8;
+  }
   return 0;
 }
 

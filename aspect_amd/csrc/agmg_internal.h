@@ -63,6 +63,8 @@ struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
   // prescribed dilation (active level only): LHS term [q][cstride], with Newton its derivatives
   bool dilation = false;
   double *dil_lhs = nullptr, *dil_de = nullptr, *dil_dp = nullptr;
+  double *ell_val = nullptr;   // assembled mass rows [ell_w][ell_stride] of the level these coefficients belong to
+  int ell_stride = 0;          // 0: not assembled
   size_t bytes = 0;
 };
 
@@ -136,6 +138,10 @@ struct DeviceLevel {
   uint32_t *childrenT = nullptr;   // [2^dim][cstride of level-1]: child cell ids on this level
   bool has_transfer = false;
   bool mass_fusable = false;       // the level fits the one-workgroup fused mass smoother
+  // assembled rows of the Q1 mass operator: column structure, ELL [ell_w][ell_stride]
+  // (unused entries point at the row's own node and carry the value 0); values live in CoeffData
+  uint32_t *ell_col = nullptr;
+  int ell_w = 0, ell_stride = 0;
   size_t bytes_tables = 0, bytes_transfer = 0, bytes_constraints = 0;
   int n_dofs_v() const { return dim * n_nodes_v; }
   int n_dofs_p() const { return n_nodes_p; }
@@ -170,6 +176,10 @@ int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, cons
 // Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.
 // Stokes pressure rows are left in slots_p for launch_pull_p(..., dim, ...), or finished here with
 // epilogue *ep (one rank: the velocity fix-up and the pressure pull share one launch).
+// assembled Q1 mass rows: cd.ell_val = rows of lambda^2 (1/eta) mass matrix (set-up), and dst = epilogue(M src)
+int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffData &cd);
+int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e);
+
 // free-surface stabilisation faces of the active Stokes operator (matrix_free_operators.cc:294-333),
 // organised by node: every surface node lists the (face, local index) pairs that touch it
 struct FaceTerm {

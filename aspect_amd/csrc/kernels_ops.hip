@@ -638,6 +638,86 @@ __global__ void __launch_bounds__(256) k_mass(const CellArgs A) {
   for (int b = 0; b < NP; ++b) A.slots_p[(size_t)b * cs + cell] = pout[b];
 }
 
+// ---- assembled rows of the pressure mass matrix ------------------------------------------------
+// The Q1 mass operator has at most 3^DIM entries per row: 12 B per entry, i.e. no more bytes per
+// application than the per-q coefficient table of the matrix-free form, and one node-owner launch
+// with the vector epilogue fused instead of cell kernel + slots + pull.  Rows are assembled on the
+// device whenever the coefficients change: one thread per row walks the cells around its node in
+// the fixed order of the pull list (deterministic), computes its row of each cell matrix
+// sum_q N_b N_j (JxW lambda^2 / eta_q) and adds it to the row's entries.
+struct EllArgs {
+  const uint32_t *col;
+  double *val;
+  int n_nodes, stride;
+  const uint32_t *ptr, *list;
+};
+template <int DIM, bool PERQ, bool GEN>
+__global__ void __launch_bounds__(256) k_mass_ell_assemble(const CellArgs A, const EllArgs M) {
+  constexpr int NP = (DIM == 3) ? 8 : 4, NQ = (DIM == 3) ? 27 : 9, W = NQ;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= M.n_nodes) return;
+  const size_t cs = (size_t)A.cstride, st = (size_t)M.stride;
+  for (uint32_t k = M.ptr[n]; k < M.ptr[n + 1]; ++k) {
+    const uint32_t ent = M.list[k];
+    const int b = (int)(ent / cs);
+    const size_t cell = ent - (size_t)b * cs;
+    double det = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) det *= GEN ? 1.0 : A.hT[d * cs + cell];
+    const double scale = A.lambda * A.lambda * det;
+    const double inv_eta_c = PERQ ? 1.0 : 1.0 / A.etaT[cell];
+    double m[NP];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) m[jj] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+      const double wq = wq1(q0) * wq1(q1) * (DIM == 3 ? wq1(q2) : 1.0);
+      const double ie = PERQ ? 1.0 / A.etaT[(size_t)q * cs + cell] : inv_eta_c;
+      const double wb = n1(q0, b & 1) * n1(q1, (b >> 1) & 1) * (DIM == 3 ? n1(q2, (b >> 2) & 1) : 1.0);
+      const double f = wb * (GEN ? A.jxwT[(size_t)q * cs + cell] : wq) * scale * ie;
+#pragma unroll
+      for (int jj = 0; jj < NP; ++jj)
+        m[jj] = fma(n1(q0, jj & 1) * n1(q1, (jj >> 1) & 1) * (DIM == 3 ? n1(q2, (jj >> 2) & 1) : 1.0), f, m[jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+      const uint32_t idx = A.cnpT[jj * cs + cell];
+      if ((idx >> 29) & 1u) continue;   // constrained source entries read as zero
+      const uint32_t nj = idx & NODE_MASK;
+      for (int kk = 0; kk < W; ++kk)
+        if (M.col[kk * st + n] == nj) { M.val[kk * st + n] += m[jj]; break; }
+    }
+  }
+}
+
+__device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, const double sum, const bool con,
+                                          double &out);
+struct EllMulArgs {
+  const uint32_t *col;
+  const double *val;
+  int n_nodes, stride;
+  const uint8_t *cmask;
+  const double *src;
+  EpiArgs e;
+};
+template <int W>
+__global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= M.n_nodes) return;
+  const size_t st = (size_t)M.stride;
+  uint32_t col[W];
+  double val[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) { col[k] = M.col[k * st + n]; val[k] = M.val[k * st + n]; }
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) sum = fma(val[k], M.src[col[k]], sum);
+  const bool con = M.cmask ? (M.cmask[n] & 1u) : false;
+  double out;
+  if (epi_value(M.e, (size_t)n, sum, con, out)) M.e.dst[n] = out;
+}
+
 // ---- fused Chebyshev smoother of the mass operator, one workgroup (agmg_internal.h) ----------
 struct MassSmArgs {
   const uint32_t *ptr, *list;
@@ -1367,6 +1447,37 @@ int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
   if (L.dim == 3) { if (gen) AGMG_MASS_LAUNCH(3, true); else AGMG_MASS_LAUNCH(3, false); }
   else { if (gen) AGMG_MASS_LAUNCH(2, true); else AGMG_MASS_LAUNCH(2, false); }
 #undef AGMG_MASS_LAUNCH
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffData &cd) {
+  if (!cd.set || !L.ell_col || !cd.ell_val) { set_error("mass rows: tables missing"); return -4; }
+  AGMG_HIP_CHECK(hipMemsetAsync(cd.ell_val, 0, (size_t)L.ell_w * L.ell_stride * sizeof(double), s));
+  const CellArgs a = make_args(L, cd, nullptr, nullptr, nullptr, nullptr);
+  const EllArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.pull_ptr_p, L.pull_list_p};
+  const dim3 grid((L.n_nodes_p + 255) / 256), block(256);
+  const bool perq = cd.nqv > 1;
+  const bool gen = L.geom == AGMG_GEOM_GENERAL;
+#define AGMG_ELL_LAUNCH(D, G)                                                                      \
+  do {                                                                                             \
+    if (perq) hipLaunchKernelGGL((k_mass_ell_assemble<D, true, G>), grid, block, 0, s, a, m);      \
+    else hipLaunchKernelGGL((k_mass_ell_assemble<D, false, G>), grid, block, 0, s, a, m);          \
+  } while (0)
+  if (L.dim == 3) { if (gen) AGMG_ELL_LAUNCH(3, true); else AGMG_ELL_LAUNCH(3, false); }
+  else { if (gen) AGMG_ELL_LAUNCH(2, true); else AGMG_ELL_LAUNCH(2, false); }
+#undef AGMG_ELL_LAUNCH
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e) {
+  if (!L.ell_col || !cd.ell_val || cd.ell_stride != L.ell_stride) { set_error("mass rows not assembled"); return -4; }
+  if (L.n_nodes_p <= 0) return 0;
+  const EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e};
+  const dim3 grid((L.n_nodes_p + 255) / 256), block(256);
+  if (L.dim == 3) hipLaunchKernelGGL((k_mass_ell<27>), grid, block, 0, s, m);
+  else hipLaunchKernelGGL((k_mass_ell<9>), grid, block, 0, s, m);
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -270,6 +270,7 @@ def test_fused_mass_smoother_matches_unfused(name, hip_lib, monkeypatch):
     """small levels run whole Chebyshev sequences of the Schur mass smoother in one launch
     (k_mass_smoother); same arithmetic as the launch-per-application path."""
     p = PROBLEMS[name]().build()
+    monkeypatch.setenv("AGMG_NO_ELL", "1")     # both through the matrix-free cell arithmetic
     monkeypatch.setenv("AGMG_NO_FUSED", "1")
     a = capi.Solver(hip_lib, p, coarse_on_host=0)
     monkeypatch.setenv("AGMG_NO_FUSED", "0")
@@ -279,6 +280,31 @@ def test_fused_mass_smoother_matches_unfused(name, hip_lib, monkeypatch):
     assert relerr(vb, va) < 1e-13
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("name", ["nsinker_r2_perq", "nsinker_r2_harmonic", "box3d_r3_freeslip", "box2d_r3_freeslip",
+                                  "deformed3d_r3_perq", "deformed2d_r3_perq", "periodic2d_r4"])
+def test_assembled_mass_rows_match_matrix_free(name, hip_lib, oracle_lib, monkeypatch):
+    """The Q1 mass operator runs from rows assembled on the device (k_mass_ell); the matrix-free cell
+    kernel + pull (AGMG_NO_ELL=1) and the oracle give the same operator on every level."""
+    p = PROBLEMS[name]().build()
+    monkeypatch.setenv("AGMG_NO_FUSED", "1")
+    monkeypatch.setenv("AGMG_NO_ELL", "1")
+    a = capi.Solver(hip_lib, p, coarse_on_host=0)
+    monkeypatch.setenv("AGMG_NO_ELL", "0")
+    b = capi.Solver(hip_lib, p, coarse_on_host=0)
+    o = capi.Solver(oracle_lib, p)
+    for level in list(range(p.hier.n_levels)) + [capi.ACTIVE]:
+        src = rand_vec(a.size(capi.OP_MASS, level), 90 + (level if level != capi.ACTIVE else 0), p.hier.finest, zero_constrained=False)
+        va, vb, vo = (s.vmult(capi.OP_MASS, src, level) for s in (a, b, o))
+        assert relerr(vb, va) < 1e-13 and relerr(vb, vo) < RTOL
+    src = rand_vec(a.size(capi.OP_MASS), 9, p.hier.finest, zero_constrained=False)
+    for s in (a, b, o):
+        s.setup_smoothers()
+    assert relerr(b.vcycle(capi.OP_MASS, src), o.vcycle(capi.OP_MASS, src)) < 1e-9
+    assert relerr(b.vcycle(capi.OP_MASS, src), a.vcycle(capi.OP_MASS, src)) < 1e-9
+    for s in (a, b, o):
+        s.close()
 
 
 def test_idr_and_expensive_paths(hip_lib, oracle_lib):
