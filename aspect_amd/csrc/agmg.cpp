@@ -805,7 +805,7 @@ int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
     SmootherProgram p;
     program_vmult(sm[1][l], p);
     for (int i = 1; i < steps; ++i) program_step(sm[1][l], p);
-    return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, nullptr, mg_sol[1][l], nullptr);
+    return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, nullptr, mg_sol[1][l], nullptr, mass_ell(L[l], L[l].coeff));
   }
   CHECK(cheb_vmult(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   for (int i = 1; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
@@ -816,7 +816,7 @@ int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
   if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
     SmootherProgram p;
     for (int i = 0; i < steps; ++i) program_step(sm[1][l], p);
-    return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, mg_sol[1][l], mg_sol[1][l], nullptr);
+    return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, mg_sol[1][l], mg_sol[1][l], nullptr, mass_ell(L[l], L[l].coeff));
   }
   for (int i = 0; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   return 0;
@@ -881,7 +881,7 @@ int agmg_ctx::level_v_step(int which, int l) {
     program_vmult(sm[1][l], p);
     for (int i = 1; i < sm_steps; ++i) program_step(sm[1][l], p);
     p.s[p.n++] = {0.0, 0.0, SM_RESID, 0};
-    CHECK(launch_mass_smoother(stream, F, F.coeff, p, F.inv_diag_M, mg_def[1][l], nullptr, mg_sol[1][l], mg_t[1][l]));
+    CHECK(launch_mass_smoother(stream, F, F.coeff, p, F.inv_diag_M, mg_def[1][l], nullptr, mg_sol[1][l], mg_t[1][l], mass_ell(F, F.coeff)));
   } else {
   CHECK(smoother_apply(which, l, mg_def[which][l]));
   {  // t = defect - A solution

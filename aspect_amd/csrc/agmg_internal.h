@@ -214,7 +214,8 @@ struct SmootherProgram { int n = 0; SmootherStep s[SM_MAX_STEPS]; };
 constexpr int MS_THREADS = 1024, MS_MAX_SLOTS = 4096, MS_MAX_NODES = 768;
 // x_in == nullptr: the program starts with SM_POINTWISE; resid_out receives b - M x of an SM_RESID step
 int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SmootherProgram &prog,
-                         const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out);
+                         const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out,
+                         bool use_ell = false);   // use_ell: from the assembled rows (k_mass_smoother_ell)
 
 // ---- transfer (kernels_transfer.hip) ----
 int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,

@@ -839,6 +839,57 @@ __global__ void __launch_bounds__(MS_THREADS) k_mass_smoother(const CellArgs A, 
   if (is_node) M.x_out[t] = x;
 }
 
+// the same smoother sequence from the assembled rows (k_mass_ell's arithmetic): the thread's row stays
+// in registers, the iterate ping-pongs between two LDS copies, one barrier per step
+template <int W>
+__global__ void __launch_bounds__(MS_THREADS) k_mass_smoother_ell(const EllMulArgs E, const MassSmArgs M,
+                                                                   const SmootherProgram P) {
+  __shared__ double X[2][MS_MAX_NODES];
+  const int t = threadIdx.x;
+  const bool is_node = t < M.n_nodes;
+  const size_t st = (size_t)E.stride;
+  uint32_t col[W];
+  double val[W];
+  double x = 0.0, xo = 0.0, bv = 0.0, dv = 0.0;
+  bool con = false;
+  if (is_node) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) { col[k] = E.col[k * st + t]; val[k] = E.val[k * st + t]; }
+    bv = M.b[t];
+    dv = M.dinv[t];
+    con = M.cmask ? (M.cmask[t] & 1u) : false;
+    if (M.x_in) x = M.x_in[t];
+    X[0][t] = x;
+  }
+  int cur = 0;
+  __syncthreads();
+  for (int sidx = 0; sidx < P.n; ++sidx) {
+    const SmootherStep S = P.s[sidx];
+    if (is_node) {
+      if (S.kind == SM_POINTWISE) {
+        x = S.f2 * dv * bv;
+      } else {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) sum = fma(val[k], X[cur][col[k]], sum);
+        const double Ax = con ? x : sum;
+        if (S.kind == SM_RESID) {
+          M.resid_out[t] = bv - Ax;
+        } else {
+          double v = fma(S.f2 * dv, bv - Ax, (1.0 + S.f1) * x);
+          if (S.use_xold) v = fma(-S.f1, xo, v);
+          xo = x;
+          x = v;
+        }
+      }
+      X[cur ^ 1][t] = x;
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (is_node) M.x_out[t] = x;
+}
+
 // ---- diagonals -------------------------------------------------------------------------
 // velocity: lane per (cell, local node); entry (a, c) = sum_q JxW eta (|grad phi|^2 + (d_c phi)^2
 //           [- 2/3 (d_c phi)^2 if compressible])
@@ -1483,12 +1534,21 @@ int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, co
 }
 
 int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SmootherProgram &prog,
-                         const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out) {
+                         const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out,
+                         bool use_ell) {
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (!L.mass_fusable || prog.n < 1 || prog.n > SM_MAX_STEPS) { set_error("fused mass smoother: level or program does not fit"); return -1; }
   const CellArgs a = make_args(L, cd, nullptr, nullptr, nullptr, nullptr);
   const MassSmArgs m{L.pull_ptr_p, L.pull_list_p, L.cmask_p, dinv, b, x_in, x_out, resid_out, L.n_nodes_p};
   const dim3 grid(1), block(MS_THREADS);
+  if (use_ell) {
+    if (!L.ell_col || !cd.ell_val || cd.ell_stride != L.ell_stride) { set_error("mass rows not assembled"); return -4; }
+    const EllMulArgs em{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, nullptr, EpiArgs()};
+    if (L.dim == 3) hipLaunchKernelGGL((k_mass_smoother_ell<27>), grid, block, 0, s, em, m, prog);
+    else hipLaunchKernelGGL((k_mass_smoother_ell<9>), grid, block, 0, s, em, m, prog);
+    AGMG_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   const bool perq = cd.nqv > 1, gen = L.geom == AGMG_GEOM_GENERAL;
 #define AGMG_MS_LAUNCH(D, G)                                                                     \
   do {                                                                                           \

@@ -266,11 +266,13 @@ def test_device_coarse_level_matches_host_coarse(hip_lib):
 
 
 @pytest.mark.parametrize("name", ["nsinker_r2_perq", "nsinker_r2_harmonic", "box2d_r3_freeslip", "deformed3d_r3_perq", "deformed2d_r3_perq"])
-def test_fused_mass_smoother_matches_unfused(name, hip_lib, monkeypatch):
+@pytest.mark.parametrize("no_ell", ["1", "0"])
+def test_fused_mass_smoother_matches_unfused(name, no_ell, hip_lib, monkeypatch):
     """small levels run whole Chebyshev sequences of the Schur mass smoother in one launch
-    (k_mass_smoother); same arithmetic as the launch-per-application path."""
+    (k_mass_smoother from the cell arithmetic, k_mass_smoother_ell from the assembled rows); same
+    arithmetic as the respective launch-per-application path."""
     p = PROBLEMS[name]().build()
-    monkeypatch.setenv("AGMG_NO_ELL", "1")     # both through the matrix-free cell arithmetic
+    monkeypatch.setenv("AGMG_NO_ELL", no_ell)
     monkeypatch.setenv("AGMG_NO_FUSED", "1")
     a = capi.Solver(hip_lib, p, coarse_on_host=0)
     monkeypatch.setenv("AGMG_NO_FUSED", "0")
