@@ -1852,7 +1852,9 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   c->diag_ready = false; c->smoothers_ready = false;
   // assembled rows of the mass operator with these coefficients (MassMatrixOperator of this level)
   if (cd.ell_stride != lv.ell_stride) { c->dfree(cd.ell_val); cd.ell_stride = 0; }
-  if (lv.ell_col && c->use_ell && !c->dist()) {
+  // (not for the active-mesh coefficients: the solve only applies the level operators' mass
+  // matrices; an active-mesh mass vmult keeps the matrix-free kernels)
+  if (lv.ell_col && c->use_ell && !c->dist() && level != AGMG_ACTIVE) {
     if (!cd.ell_val) CHECK(c->dalloc(&cd.ell_val, (size_t)lv.ell_w * lv.ell_stride));
     cd.ell_stride = lv.ell_stride;
     CHECK(launch_mass_ell_assemble(c->stream, lv, cd));

@@ -657,6 +657,10 @@ __global__ void __launch_bounds__(256) k_mass_ell_assemble(const CellArgs A, con
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= M.n_nodes) return;
   const size_t cs = (size_t)A.cstride, st = (size_t)M.stride;
+  uint32_t col[W];
+  double val[W];
+#pragma unroll
+  for (int kk = 0; kk < W; ++kk) { col[kk] = M.col[kk * st + n]; val[kk] = 0.0; }
   for (uint32_t k = M.ptr[n]; k < M.ptr[n + 1]; ++k) {
     const uint32_t ent = M.list[k];
     const int b = (int)(ent / cs);
@@ -685,10 +689,18 @@ __global__ void __launch_bounds__(256) k_mass_ell_assemble(const CellArgs A, con
       const uint32_t idx = A.cnpT[jj * cs + cell];
       if ((idx >> 29) & 1u) continue;   // constrained source entries read as zero
       const uint32_t nj = idx & NODE_MASK;
-      for (int kk = 0; kk < W; ++kk)
-        if (M.col[kk * st + n] == nj) { M.val[kk * st + n] += m[jj]; break; }
+      // (unused entries of the row repeat the row's own node n: only the first match may take the value)
+      bool placed = false;
+#pragma unroll
+      for (int kk = 0; kk < W; ++kk) {
+        const bool hit = !placed && col[kk] == nj;
+        val[kk] += hit ? m[jj] : 0.0;
+        placed = placed || hit;
+      }
     }
   }
+#pragma unroll
+  for (int kk = 0; kk < W; ++kk) M.val[kk * st + n] = val[kk];
 }
 
 __device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, const double sum, const bool con,
@@ -1504,7 +1516,8 @@ int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
 
 int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffData &cd) {
   if (!cd.set || !L.ell_col || !cd.ell_val) { set_error("mass rows: tables missing"); return -4; }
-  AGMG_HIP_CHECK(hipMemsetAsync(cd.ell_val, 0, (size_t)L.ell_w * L.ell_stride * sizeof(double), s));
+  if (L.ell_stride > L.n_nodes_p)   // padding rows
+    AGMG_HIP_CHECK(hipMemsetAsync(cd.ell_val, 0, (size_t)L.ell_w * L.ell_stride * sizeof(double), s));
   const CellArgs a = make_args(L, cd, nullptr, nullptr, nullptr, nullptr);
   const EllArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.pull_ptr_p, L.pull_list_p};
   const dim3 grid((L.n_nodes_p + 255) / 256), block(256);

@@ -46,18 +46,20 @@ struct ProlArgs {
   double *dst;
 };
 
-// K: polynomial degree (2 velocity, 1 pressure); NC: components per node
+// K: polynomial degree (2 velocity, 1 pressure); NC: components per node.  One thread per fine
+// node: the parent's node indices and the weights serve all NC components.
 template <int DIM, int K, int NC>
 __global__ void __launch_bounds__(256) k_prolongate_add(const ProlArgs A) {
   constexpr int N1 = K + 1, NF = 2 * K + 1;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)A.n_fine_nodes * NC) return;
-  const int node = (int)(t / NC), c = (int)(t - (long)node * NC);
+  const int node = blockIdx.x * 256 + threadIdx.x;
+  if (node >= A.n_fine_nodes) return;
   const uint32_t par = A.parent[node];
   int pos = A.pos[node];
   int r[3] = {0, 0, 0};
   for (int d = 0; d < DIM; ++d) { r[d] = pos % NF; pos /= NF; }
-  double val = 0.0;
+  double val[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) val[c] = 0.0;
   for (int i2 = 0; i2 < (DIM == 3 ? N1 : 1); ++i2) {
     const double w2 = (DIM == 3) ? prow<K>(r[2], i2) : 1.0;
     if (w2 == 0.0) continue;
@@ -69,12 +71,16 @@ __global__ void __launch_bounds__(256) k_prolongate_add(const ProlArgs A) {
         if (w == 0.0) continue;
         const int a = i0 + N1 * (i1 + N1 * i2);
         const uint32_t idx = A.cnT[(size_t)a * A.cstride_c + par];
-        if ((idx >> (29 + c)) & 1u) continue;  // coarse Dirichlet value reads as zero
-        val = fma(w, A.src[(size_t)(idx & NODE_MASK) * NC + c], val);
+        const double *sp = A.src + (size_t)(idx & NODE_MASK) * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (!((idx >> (29 + c)) & 1u)) val[c] = fma(w, sp[c], val[c]);  // coarse Dirichlet values read as zero
       }
     }
   }
-  A.dst[t] += val;
+  double *dp = A.dst + (size_t)node * NC;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) dp[c] += val[c];
 }
 
 struct RestrArgs {
@@ -164,8 +170,7 @@ int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLe
   a.cstride_c = coarse.cstride;
   a.src = src_coarse;
   a.dst = dst_fine;
-  const int nc = velocity ? fine.dim : 1;
-  const long n = (long)a.n_fine_nodes * nc;
+  const long n = a.n_fine_nodes;
   if (n <= 0) return 0;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (fine.dim == 3) {
