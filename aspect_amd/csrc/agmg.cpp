@@ -285,6 +285,7 @@ struct agmg_ctx {
   int prolongate_from(int which, int l, double *dst_fine, const double *src_coarse);
   int global_multiplicity(const Exchange &x, const std::vector<uint32_t> &send_nodes_h, std::vector<double> &mult);
   std::vector<std::vector<uint32_t>> send_nodes_h[2];   // [velocity|pressure][level]: host copy of Exchange::send_nodes
+  std::vector<uint32_t> gid_fin_h[2];                   // [pressure|velocity]: global node ids of the finest level (host)
 };
 
 // ===================================================================== memory / setup
@@ -1398,11 +1399,27 @@ int solver_idr(agmg_ctx *c, const Op &A, const Op &P, double *x, const double *b
   std::mt19937 rng(5489u);
   std::normal_distribution<double> nd(0.0, 1.0);
   std::vector<double> hq(n);
+  // Distributed: the shadow vectors are defined by GLOBAL dof index (every rank draws the whole
+  // serial sequence and keeps its own entries), so that iteration counts do not depend on the
+  // partition.  (deal.II draws per rank; its parallel IDR runs are partition dependent.)
+  const DeviceLevel &lf = c->fin();
+  const bool by_gid = c->dist() && c->gid_fin_h[1].size() == (size_t)lf.n_nodes_v && c->gid_fin_h[0].size() == (size_t)lf.n_nodes_p;
+  double ng[2] = {(double)lf.n_owned_v, (double)lf.n_owned_p};   // global node counts
+  if (by_gid) CHECK(c->allreduce_host(ng, 2));
+  std::vector<double> hglob(by_gid ? (size_t)ng[0] * lf.dim + (size_t)ng[1] : 0);
   for (int i = 0; i < s; ++i) {
     CHECK(vec_set(st, G[i], 0.0, n));
     CHECK(vec_set(st, U[i], 0.0, n));
     if (i != 0) {
-      for (auto &e : hq) e = nd(rng);
+      if (by_gid) {
+        for (auto &e : hglob) e = nd(rng);
+        const size_t nu_l = (size_t)lf.n_nodes_v * lf.dim, nu_g = (size_t)ng[0] * lf.dim;
+        for (int node = 0; node < lf.n_nodes_v; ++node)
+          for (int cc = 0; cc < lf.dim; ++cc) hq[(size_t)node * lf.dim + cc] = hglob[(size_t)c->gid_fin_h[1][node] * lf.dim + cc];
+        for (int node = 0; node < lf.n_nodes_p; ++node) hq[nu_l + node] = hglob[nu_g + c->gid_fin_h[0][node]];
+      } else {
+        for (auto &e : hq) e = nd(rng);
+      }
       CHECK(c->h2d(Q[i], hq.data(), n));
     } else CHECK(vec_copy(st, Q[i], r, n));
     for (int j = 0; j < i; ++j) {
@@ -1508,9 +1525,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (opt->degree_v != 2) { set_error("only Stokes velocity polynomial degree 2 (Q2-Q1) is built"); return nullptr; }
   if (opt->n_levels < 1) { set_error("n_levels must be >= 1"); return nullptr; }
   if (opt->world_size < 1 || opt->rank < 0 || opt->rank >= opt->world_size) { set_error("bad world_size / rank"); return nullptr; }
-  if (opt->world_size > 1 && opt->krylov_type == AGMG_KRYLOV_IDR) {
-    set_error("IDR(s) in a distributed context is not built (its random shadow space is generated per rank)"); return nullptr;
-  }
+
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: this library has no CPU path"); return nullptr; }
   if (opt->device < 0 || opt->device >= ndev) { set_error("bad device ordinal"); return nullptr; }
@@ -1655,6 +1670,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     if (gn && c->dist()) {
       std::vector<uint32_t> g(gn, gn + (vel ? lv.n_nodes_v : lv.n_nodes_p));
       CHECK(c->upload(vel ? &lv.gid_v : &lv.gid_p, g));
+      if (level == c->nl() - 1) c->gid_fin_h[vel] = g;
     }
   }
   for (int vel = 0; vel < 2; ++vel) {

@@ -32,6 +32,8 @@ def global_problem(case, world):
     reps = {1: [1, 1, 1], 2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}[world]
     if case == "nsinker":
         p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE)
+    elif case == "nsinker_idr":   # SolverIDR(2) as the cheap solver (tests/nsinker_gmg_idr.prm)
+        p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, krylov="idr", tol=1e-7, n_cheap=1000, n_expensive=1000)
     elif case == "nsinker_harmonic":
         p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4)
     elif case == "box3d":
@@ -135,7 +137,8 @@ def main():
         # the whole solve
         xg, rg, _ = hip.solve()
         xo, ro, _ = ora.solve()
-        if abs(rg.n_cheap_iterations - ro.n_cheap_iterations) > 1:
+        # (IDR's short recurrences react to the summation order of the distributed dot products)
+        if abs(rg.n_cheap_iterations - ro.n_cheap_iterations) > (3 if g.krylov == "idr" else 1):
             fails.append(f"iterations {rg.n_cheap_iterations} vs {ro.n_cheap_iterations}")
         nu_o = fin.n_owned_nodes_v * fin.dim
         lo_, go_ = fin.owned_dofs_v()
