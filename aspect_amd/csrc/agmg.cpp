@@ -143,6 +143,7 @@ struct agmg_ctx {
   FaceTerm faces;   // free-surface stabilisation faces of the active Stokes operator
   void free_faces() {
     dfree(faces.nodes); dfree(faces.ptr); dfree(faces.ent); dfree(faces.fnode); dfree(faces.stab); dfree(faces.njxw);
+    dfree(faces.exp_nodes); dfree(faces.exp_ptr); dfree(faces.exp_ent);
     faces = FaceTerm();
   }
   double *slots_u = nullptr, *slots_p = nullptr;
@@ -717,7 +718,15 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
   add_compress(m, lv.xp, 1);
   CHECK(exchange(m));
   CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_OWNED));
-  return launch_pull_p(stream, lv, slots_p, lv.dim, ep, PH_OWNED);
+  CHECK(launch_pull_p(stream, lv, slots_p, lv.dim, ep, PH_OWNED));
+  if (!faces.global_active) return 0;
+  // boundary-face loop (matrix_free_operators.cc:343-353): the sums of the local faces go to the owned
+  // rows directly; those of ghost rows travel to their owners in one more compress step
+  const double sign = eu_in.epi == EPI_RESID ? -1.0 : 1.0;
+  if (lv.xv.n_ghost) AGMG_HIP_CHECK(hipMemsetAsync(lv.xv.ghostbuf, 0, (size_t)lv.xv.n_ghost * lv.xv.nc * sizeof(double), stream));
+  CHECK(launch_face_term(stream, lv.dim, faces, lv.cmask_v, src, dst, sign, lv.xv.ghostbuf, lv.n_owned_v));
+  CHECK(compress(lv.xv));
+  return launch_face_add_received(stream, lv.dim, faces, lv.cmask_v, lv.xv.expbuf, dst, sign);
 }
 int agmg_ctx::stokes_vmult(double *dst, const double *src) {
   EpiArgs e;
@@ -1884,8 +1893,26 @@ int agmg_set_free_surface_faces(agmg_ctx *c, const agmg_face_data *d) {
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   CHECK(c->sync());
   c->free_faces();
+  if (c->dist()) {   // collective: every rank calls this, also ranks without faces
+    double n = d ? (double)d->n_faces : 0.0;
+    CHECK(c->allreduce_host(&n, 1));
+    c->faces.global_active = n > 0;
+    if (c->faces.global_active && !c->L.empty() && c->fin().set) {
+      // owned nodes that other ranks ghost -> their entries of the receive buffer
+      const std::vector<uint32_t> &sn = c->send_nodes_h[0][c->nl() - 1];
+      std::map<uint32_t, std::vector<uint32_t>> by_node;
+      for (size_t k = 0; k < sn.size(); ++k) by_node[sn[k]].push_back((uint32_t)k);
+      std::vector<uint32_t> en, ep(1, 0), ee;
+      for (auto &kv : by_node) {
+        en.push_back(kv.first);
+        ee.insert(ee.end(), kv.second.begin(), kv.second.end());
+        ep.push_back((uint32_t)ee.size());
+      }
+      CHECK(c->upload(&c->faces.exp_nodes, en)); CHECK(c->upload(&c->faces.exp_ptr, ep)); CHECK(c->upload(&c->faces.exp_ent, ee));
+      c->faces.n_exp_nodes = (int)en.size();
+    }
+  }
   if (!d || d->n_faces == 0) return 0;
-  if (c->dist()) { set_error("free-surface faces are not available in a distributed context yet"); return -2; }
   if (d->n_faces < 0 || !d->face_cell || !d->face_number || !d->stabilization_term) { set_error("free-surface face tables missing"); return -1; }
   if ((d->normal == nullptr) != (d->jxw == nullptr)) { set_error("face normal and jxw come together"); return -1; }
   if (c->L.empty() || !c->fin().set) { set_error("set_free_surface_faces before set_level"); return -1; }

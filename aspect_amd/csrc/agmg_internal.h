@@ -190,10 +190,20 @@ struct FaceTerm {
   uint32_t *fnode = nullptr;   // [n_faces][3^(dim-1)] nodes of each face
   double *stab = nullptr;      // [n_faces][nqf][dim] pressure_perturbation * g_hat
   double *njxw = nullptr;      // [n_faces][nqf][dim] outward normal * JxW
+  // distributed contexts: some rank holds faces (agreed by all ranks at set-up); owned nodes other
+  // ranks ghost, with their entries of the receive buffer (CSR), for the sums coming back
+  bool global_active = false;
+  int n_exp_nodes = 0;
+  uint32_t *exp_nodes = nullptr, *exp_ptr = nullptr, *exp_ent = nullptr;
 };
-// dst_u += sign * (face term applied to src_u), unconstrained rows only
+// dst_u += sign * (face term applied to src_u), unconstrained rows only.  ghost_out != nullptr
+// (distributed): the sums of ghost nodes (index >= n_owned) go, unsigned, to
+// ghost_out[(node - n_owned) * dim + c] for the compress step instead.
 int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *src_u,
-                     double *dst_u, double sign);
+                     double *dst_u, double sign, double *ghost_out = nullptr, int n_owned = 0);
+// dst_u[node] += sign * (sum of the node's receive-buffer entries), fixed order, unconstrained rows
+int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *recv,
+                             double *dst_u, double sign);
 
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,

@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(256) k_fix_pull(const FixArgs F, const PullArg
 template <int DIM>
 __global__ void __launch_bounds__(128) k_face_term(const FaceTerm F, const uint8_t *__restrict__ cmask,
                                                    const double *__restrict__ src, double *__restrict__ dst,
-                                                   const double sign) {
+                                                   const double sign, double *__restrict__ ghost_out, const int n_owned) {
   constexpr int NF = DIM == 3 ? 9 : 3, NQF = NF;
   const int s = blockIdx.x * 128 + threadIdx.x;
   if (s >= F.n_nodes) return;
@@ -1369,10 +1369,35 @@ __global__ void __launch_bounds__(128) k_face_term(const FaceTerm F, const uint8
       for (int c = 0; c < DIM; ++c) val[c] = fma(-pa * gu, nj[c], val[c]);
     }
   }
+  if (ghost_out && (int)node >= n_owned) {   // another rank owns the row: its share of the sum travels
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) ghost_out[(size_t)((int)node - n_owned) * DIM + c] = val[c];
+    return;
+  }
   const uint8_t m = cmask[node];
 #pragma unroll
   for (int c = 0; c < DIM; ++c)
     if (!((m >> c) & 1)) dst[(size_t)node * DIM + c] += sign * val[c];
+}
+template <int DIM>
+__global__ void __launch_bounds__(128) k_face_add_received(const FaceTerm F, const uint8_t *__restrict__ cmask,
+                                                           const double *__restrict__ recv, double *__restrict__ dst,
+                                                           const double sign) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= F.n_exp_nodes) return;
+  const uint32_t node = F.exp_nodes[i];
+  double sum[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) sum[c] = 0.0;
+  for (uint32_t k = F.exp_ptr[i]; k < F.exp_ptr[i + 1]; ++k) {
+    const double *p = recv + (size_t)F.exp_ent[k] * DIM;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) sum[c] += p[c];
+  }
+  const uint8_t m = cmask[node];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c)
+    if (!((m >> c) & 1)) dst[(size_t)node * DIM + c] += sign * sum[c];
 }
 
 CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
@@ -1465,11 +1490,20 @@ int launch_blk_op(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiA
 }  // namespace
 
 int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *src_u,
-                     double *dst_u, double sign) {
+                     double *dst_u, double sign, double *ghost_out, int n_owned) {
   if (ft.n_nodes <= 0) return 0;
   const dim3 grid((ft.n_nodes + 127) / 128), block(128);
-  if (dim == 3) hipLaunchKernelGGL((k_face_term<3>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign);
-  else hipLaunchKernelGGL((k_face_term<2>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign);
+  if (dim == 3) hipLaunchKernelGGL((k_face_term<3>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign, ghost_out, n_owned);
+  else hipLaunchKernelGGL((k_face_term<2>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign, ghost_out, n_owned);
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *recv,
+                             double *dst_u, double sign) {
+  if (ft.n_exp_nodes <= 0) return 0;
+  const dim3 grid((ft.n_exp_nodes + 127) / 128), block(128);
+  if (dim == 3) hipLaunchKernelGGL((k_face_add_received<3>), grid, block, 0, s, ft, cmask_v, recv, dst_u, sign);
+  else hipLaunchKernelGGL((k_face_add_received<2>), grid, block, 0, s, ft, cmask_v, recv, dst_u, sign);
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -171,6 +171,18 @@ class LocalProblem:
         self.eta_levels = [np.ascontiguousarray(t[lev.cells]) for t, lev in zip(gproblem.eta_levels, self.hier.levels)]
         self.eta_active = np.ascontiguousarray(gproblem.eta_active[self.hier.finest.cells])
         fin = self.hier.finest
+        # free-surface faces of this rank's cells (every rank passes its list, possibly empty: the
+        # call is collective in a distributed context)
+        self.free_surface = None
+        fs = getattr(gproblem, "free_surface", None)
+        if fs is not None:
+            cells_g, fnos, stab, normal, jxw = fs
+            lut = -np.ones(gproblem.hier.finest.n_cells, dtype=np.int64)
+            lut[np.asarray(fin.cells, dtype=np.int64)] = np.arange(len(fin.cells))
+            loc = lut[np.asarray(cells_g, dtype=np.int64)]
+            keep = loc >= 0
+            self.free_surface = (loc[keep].astype(np.uint32), fnos[keep], stab[keep],
+                                 None if normal is None else normal[keep], None if jxw is None else jxw[keep])
         if hasattr(gproblem, "rhs_u"):
             self.rhs_u = fin.to_local_v(gproblem.rhs_u)
             self.rhs_p = fin.to_local_p(gproblem.rhs_p)

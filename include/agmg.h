@@ -248,8 +248,10 @@ int agmg_set_coefficients(agmg_ctx *ctx, int level, const agmg_cell_data *data);
  * matrix_free_operators.cc:294-333; apply_add :337-358): dst_u += sum over the
  * listed faces of integral phi_i . (-(g . u) n).  Active Stokes operator only
  * (the reference has no multilevel surface terms, local_smoothing.cc:668-670);
- * data == NULL or n_faces == 0 removes it.  Not available in a distributed
- * context yet. */
+ * data == NULL or n_faces == 0 removes it.  In a distributed context the call
+ * is collective: every rank passes the faces of its own cells (possibly none);
+ * sums that belong to rows of other ranks travel in one more compress step per
+ * operator application. */
 int agmg_set_free_surface_faces(agmg_ctx *ctx, const agmg_face_data *data);
 
 /* build_preconditioner(): ABlockOperator/MassMatrixOperator::compute_diagonal on

@@ -34,6 +34,8 @@ def global_problem(case, world):
         p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE)
     elif case == "nsinker_idr":   # SolverIDR(2) as the cheap solver (tests/nsinker_gmg_idr.prm)
         p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, krylov="idr", tol=1e-7, n_cheap=1000, n_expensive=1000)
+    elif case == "free_surface":  # free top and x+ boundaries carrying the stabilisation face term
+        p = cases.free_surface_blob(3, 2, side_surface=True)
     elif case == "nsinker_harmonic":
         p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4)
     elif case == "box3d":

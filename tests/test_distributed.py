@@ -63,6 +63,7 @@ def test_world_size_2_gloo_partition_and_transport():
 @pytest.mark.parametrize("nproc,case,wire", [(2, "nsinker", "gloo"), (4, "nsinker_harmonic", "gloo"), (8, "box3d", "gloo"),
                                              (2, "deformed", "gloo"), (4, "box2d", "gloo"),
                                              (2, "nsinker_idr", "gloo"), (4, "nsinker_idr", "gloo-dev"),
+                                             (2, "free_surface", "gloo"), (8, "free_surface", "gloo-dev"),
                                              # device-pointer protocol of the communicator (what RCCL uses)
                                              (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
 def test_distributed_hip_matches_serial_oracle(nproc, case, wire):
