@@ -1165,7 +1165,18 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   const int c = lane - j * DIM;
   const bool lane_ok = j < CPW;
   if (!lane_ok) j = CPW - 1;
+  // XCD affinity: workgroups with the same blockIdx % 8 share an XCD (and its L2), so each of the
+  // 8 groups takes a contiguous run of blocks, i.e. a compact part of the mesh whose blocks re-read
+  // each other's halo nodes (a speed choice only: any placement is correct)
+#if AGMG_ABLATE & 256
   const int blk = blockIdx.x;
+#else
+  int blk;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    blk = (int)((x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i);
+  }
+#endif
   const int c0 = blk * BC;
   const int cell_l = c0 + wave * CPW + j;
   const int cell = cell_l < A.n_cells ? cell_l : A.n_cells - 1;
