@@ -1056,6 +1056,12 @@ __global__ void __launch_bounds__(256) k_pull(const PullArgs P) { pull_body<NC, 
 #else
 #define AGMG_STAMP(k)
 #endif
+// block index -> work item such that the 8 groups of workgroups {blockIdx % 8 = x} (one XCD, one L2
+// each) take contiguous runs of items; a bijection on [0, nb)
+__device__ __forceinline__ unsigned xcd_contiguous(const unsigned b, const unsigned nb) {
+  const unsigned q = nb >> 3, rem = nb & 7u, x = b & 7u, i = b >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
+}
 struct BlkArgs {
   unsigned long long *dbg;
   const uint4 *blk_hdr;      // per block {unique nodes, exclusive nodes, first shared slot, 0}
@@ -1171,11 +1177,7 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
 #if AGMG_ABLATE & 256
   const int blk = blockIdx.x;
 #else
-  int blk;
-  {
-    const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-    blk = (int)((x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i);
-  }
+  const int blk = (int)xcd_contiguous(blockIdx.x, gridDim.x);
 #endif
   const int c0 = blk * BC;
   const int cell_l = c0 + wave * CPW + j;
