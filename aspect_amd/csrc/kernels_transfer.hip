@@ -36,6 +36,8 @@ template <int K> __device__ __forceinline__ double prow(int r, int i) {
   }
 }
 
+template <int K> __host__ __device__ constexpr double pw(int r, int i) { return K == 2 ? p2row(r, i) : p1row(r, i); }
+
 struct ProlArgs {
   int n_fine_nodes;
   const uint32_t *parent;   // [n_fine_nodes]
@@ -83,6 +85,85 @@ __global__ void __launch_bounds__(256) k_prolongate_add(const ProlArgs A) {
   for (int c = 0; c < NC; ++c) dp[c] += val[c];
 }
 
+// Velocity prolongation on levels with many cells, the transpose of k_restrict_cells: one lane per
+// (parent cell, component) expands the parent's (K+1)^DIM values to the (2K+1)^DIM patch by sum
+// factorisation, plane by plane, and adds them to the fine nodes this parent is the designated
+// parent of (`parent[fine node] == cell` at the designated patch position: every fine node is
+// written exactly once, no atomics).
+// Uniform control flow, where the node-owner form diverges on the 1..27 weights per node.
+struct ProlCellArgs {
+  int n_coarse_cells, cstride_c, cstride_f;
+  const uint32_t *childrenT;  // [2^DIM][cstride_c]
+  const uint32_t *cnfT;       // fine  [(K+1)^DIM][cstride_f]
+  const uint32_t *cncT;       // coarse [(K+1)^DIM][cstride_c]
+  const uint32_t *parent;     // [n_fine_nodes] designated parent cell of each fine node
+  const uint8_t *pos;         // [n_fine_nodes] and its position in that parent's patch (a periodic
+                              // direction one or two cells wide puts a node into a patch twice)
+  const double *src;          // coarse vector
+  double *dst;                // fine vector
+};
+template <int DIM, int K, int NC>
+__global__ void __launch_bounds__(256) k_prolongate_cells(const ProlCellArgs A) {
+  constexpr int N1 = K + 1, NF = 2 * K + 1, NLOC = (DIM == 3) ? N1 * N1 * N1 : N1 * N1, NCH = 1 << DIM;
+  constexpr int NZ = (DIM == 3) ? NF : 1, NZC = (DIM == 3) ? N1 : 1;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)A.n_coarse_cells * NC) return;
+  const int cell = (int)(t / NC), c = (int)(t - (long)cell * NC);
+  uint32_t ch[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) ch[k] = A.childrenT[(size_t)k * A.cstride_c + cell];
+  double cv[NLOC];
+#pragma unroll
+  for (int a = 0; a < NLOC; ++a) {
+    const uint32_t idx = A.cncT[(size_t)a * A.cstride_c + cell];
+    const double v = A.src[(size_t)(idx & NODE_MASK) * NC + c];
+    cv[a] = ((idx >> (29 + c)) & 1u) ? 0.0 : v;   // coarse Dirichlet values read as zero
+  }
+#pragma unroll
+  for (int r2 = 0; r2 < NZ; ++r2) {
+    const int up2 = (DIM == 3 && r2 > K) ? 1 : 0;
+    double pl[N1][N1];   // the coarse values interpolated to fine plane r2
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+      for (int i0 = 0; i0 < N1; ++i0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i2 = 0; i2 < NZC; ++i2) {
+          const double w = (DIM == 3) ? pw<K>(r2, i2) : 1.0;
+          if (w != 0.0) s = fma(w, cv[i0 + N1 * (i1 + N1 * i2)], s);
+        }
+        pl[i1][i0] = s;
+      }
+    double tx[N1][NF];
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+      for (int r0 = 0; r0 < NF; ++r0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < N1; ++i0)
+          if (pw<K>(r0, i0) != 0.0) s = fma(pw<K>(r0, i0), pl[i1][i0], s);
+        tx[i1][r0] = s;
+      }
+#pragma unroll
+    for (int r1 = 0; r1 < NF; ++r1)
+#pragma unroll
+      for (int r0 = 0; r0 < NF; ++r0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1)
+          if (pw<K>(r1, i1) != 0.0) s = fma(pw<K>(r1, i1), tx[i1][r0], s);
+        const int up0 = r0 > K ? 1 : 0, up1 = r1 > K ? 1 : 0;
+        const int child = up0 | (up1 << 1) | (up2 << 2);
+        const int loc = (r0 - K * up0) + N1 * (r1 - K * up1) + (DIM == 3 ? N1 * N1 * (r2 - K * up2) : 0);
+        const uint32_t fn = A.cnfT[(size_t)loc * A.cstride_f + ch[child]] & NODE_MASK;
+        const int p = r0 + NF * (r1 + NF * r2);
+        if (A.parent[fn] == (uint32_t)cell && A.pos[fn] == (uint8_t)p) A.dst[(size_t)fn * NC + c] += s;
+      }
+  }
+}
+
 struct RestrArgs {
   int n_coarse_cells, cstride_c, cstride_f;
   const uint32_t *childrenT;  // [2^DIM][cstride_c]
@@ -91,8 +172,6 @@ struct RestrArgs {
   const double *src;          // fine vector
   double *slots;              // coarse slots [a][cstride_c][NC]
 };
-
-template <int K> __host__ __device__ constexpr double pw(int r, int i) { return K == 2 ? p2row(r, i) : p1row(r, i); }
 
 // One lane per (parent cell, component): the (2K+1)^DIM patch values of the children are gathered
 // once (weighted by 1/multiplicity), then restricted by sum factorisation, (2K+1) -> (K+1) per
@@ -172,6 +251,30 @@ int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLe
   a.dst = dst_fine;
   const long n = a.n_fine_nodes;
   if (n <= 0) return 0;
+  // many cells: the per-parent sum-factorised form (the summation order of a fine value differs from
+  // the node-owner form only in rounding)
+  // (AGMG_PROL_CELLS_MIN: developer/test knob for the switch-over size, read per call)
+  const char *env = getenv("AGMG_PROL_CELLS_MIN");
+  const long min_cells = env ? atol(env) : 4096;
+  if (velocity && coarse.n_cells >= min_cells) {
+    ProlCellArgs pc;
+    pc.n_coarse_cells = coarse.n_cells;
+    pc.cstride_c = coarse.cstride;
+    pc.cstride_f = fine.cstride;
+    pc.childrenT = fine.childrenT;
+    pc.cnfT = fine.cnvT;
+    pc.cncT = coarse.cnvT;
+    pc.parent = fine.prol_parent_v;
+    pc.pos = fine.prol_pos_v;
+    pc.src = src_coarse;
+    pc.dst = dst_fine;
+    const long nl = (long)coarse.n_cells * fine.dim;
+    const dim3 g((unsigned)((nl + 255) / 256)), b(256);
+    if (fine.dim == 3) hipLaunchKernelGGL((k_prolongate_cells<3, 2, 3>), g, b, 0, s, pc);
+    else hipLaunchKernelGGL((k_prolongate_cells<2, 2, 2>), g, b, 0, s, pc);
+    AGMG_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (fine.dim == 3) {
     if (velocity) hipLaunchKernelGGL((k_prolongate_add<3, 2, 3>), grid, block, 0, s, a);

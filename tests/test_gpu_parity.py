@@ -205,6 +205,23 @@ def test_transfer(pair):
             assert relerr(a, b) < RTOL
 
 
+@pytest.mark.parametrize("name", ["nsinker_r2_perq", "box3d_r3_freeslip", "box2d_r3_freeslip", "deformed3d_r3_perq", "periodic2d_r4"])
+def test_per_parent_prolongation(name, hip_lib, oracle_lib, monkeypatch):
+    """levels with many cells prolongate the velocity per parent cell (k_prolongate_cells, sum
+    factorisation); forced here on the small test levels: same result as the node-owner kernel and the oracle."""
+    p = PROBLEMS[name]()
+    g, o = make_pair(p, hip_lib, oracle_lib)
+    for level in range(1, p.hier.n_levels):
+        rng = np.random.Generator(np.random.PCG64(11 * level))
+        fine, coarse = rng.uniform(-1, 1, g.size(capi.OP_A, level)), rng.uniform(-1, 1, g.size(capi.OP_A, level - 1))
+        monkeypatch.setenv("AGMG_PROL_CELLS_MIN", "1")
+        a = g.prolongate_add(capi.OP_A, level, fine, coarse)
+        monkeypatch.setenv("AGMG_PROL_CELLS_MIN", "1000000000")
+        b = g.prolongate_add(capi.OP_A, level, fine, coarse)
+        assert relerr(a, b) < 1e-14 and relerr(a, o.prolongate_add(capi.OP_A, level, fine, coarse)) < RTOL
+    g.close(); o.close()
+
+
 def test_eigenvalue_estimates_and_vcycle(pair):
     p, g, o = pair
     g.setup_smoothers()
@@ -401,6 +418,24 @@ def test_error_paths(hip_lib):
     cd = capi.CellData()
     cd.enable_newton_derivatives = 1
     assert hip_lib.set_coefficients(s.ctx, 0, C.byref(cd)) != 0
+    # free-surface faces: missing tables, a cell or face number out of range, normals without JxW
+    fd = capi.FaceData()
+    fd.n_faces = 1
+    assert hip_lib.set_free_surface_faces(s.ctx, C.byref(fd)) != 0 and b"missing" in hip_lib.last_error()
+    cells = np.array([10 ** 6], dtype=np.uint32)
+    fnos = np.array([5], dtype=np.uint8)
+    stab = np.zeros((1, 9, 3))
+    with pytest.raises(capi.AgmgError, match="out of range"):
+        s.set_free_surface_faces(cells, fnos, stab)
+    with pytest.raises(capi.AgmgError, match="out of range"):
+        s.set_free_surface_faces(np.array([0], dtype=np.uint32), np.array([6], dtype=np.uint8), stab)
+    cell0 = np.array([0], dtype=np.uint32)
+    fd.face_cell, fd.face_number = capi._ptr(cell0, C.c_uint32), capi._ptr(fnos, C.c_uint8)
+    fd.stabilization_term, fd.normal = capi._ptr(stab, C.c_double), capi._ptr(stab, C.c_double)
+    assert hip_lib.set_free_surface_faces(s.ctx, C.byref(fd)) != 0 and b"together" in hip_lib.last_error()
+    # ... and the operator still works without faces afterwards
+    src = rand_vec(s.size(capi.OP_STOKES), 1, p.hier.finest)
+    assert np.all(np.isfinite(s.vmult(capi.OP_STOKES, src)))
     s.close()
 
 
