@@ -365,7 +365,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   const int wtile = blk_wave_tile(dim);
   const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile * 8);  // entries are LDS byte offsets
   std::vector<uint32_t> unodes((size_t)nb * max_u, 0);
-  std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot), lidT((size_t)NV * lv.cstride, 0);
+  std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot), lidT((size_t)LID_ROW * lv.cstride, 0);
   std::vector<uint8_t> cnt;
   for (int b = 0; b < nb; ++b) {
     const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
@@ -381,7 +381,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
       const int w = (cell - c0) / cpw, jj = (cell - c0) % cpw;
       for (int a = 0; a < NV; ++a) {
         const int l = lid_of[hl.cnv[(size_t)cell * NV + a]];
-        lidT[(size_t)a * lv.cstride + cell] = (uint16_t)l;
+        lidT[(size_t)cell * LID_ROW + a] = (uint16_t)l;
         if (cnt[l] >= 8) return 0;  // node of valence > 8 inside one block: keep the slot path
         uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)((w * wtile + a * BLK_SLOT_ROW + jj * dim) * 8);
       }

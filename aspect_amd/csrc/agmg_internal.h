@@ -33,6 +33,7 @@ constexpr int cells_per_wave(int dim) { return 64 / dim; }
 // row stride of the slot tile in doubles: odd, so that the node-owner reads (which differ in the
 // row a far more than in the lane) spread over the LDS banks
 constexpr int BLK_SLOT_ROW = 65;
+constexpr int LID_ROW = 32;   // uint16 entries per cell row of BlockTables::lidT (3^dim <= 27 used)
 constexpr int blk_wave_tile(int dim) {
   const int nv = dim == 3 ? 27 : 9;
   const int slots = nv * BLK_SLOT_ROW, scratch = 3 * (64 * dim + 2) + nv * cells_per_wave(dim);
@@ -81,7 +82,8 @@ struct BlockTables {
   uint32_t *blk_hdr = nullptr;    // [n_blocks][4]: unique nodes, exclusive nodes (they come first), first shared slot, 0
   uint32_t *unodes = nullptr;     // [n_blocks][max_unodes] global node | cmask << 29 of (block, local id)
   uint16_t *uent8 = nullptr;      // [n_blocks][max_unodes][8] LDS slot indices, padded with the zero slot
-  uint16_t *lidT = nullptr;       // [3^dim][cstride] local id (within its block) of each cell node
+  uint16_t *lidT = nullptr;       // [cstride][LID_ROW] local id (within its block) of each cell node: one 64-byte
+                                  // row per cell (four 16-byte loads per lane instead of 3^dim 2-byte ones)
   uint32_t *sh_nodes = nullptr;   // [n_shared] global node
   uint32_t *sh_ptr = nullptr;     // [n_shared + 1]
   uint32_t *sh_list = nullptr;    // slot positions, in block order; positions >= n_shared_slots address

@@ -1067,7 +1067,7 @@ struct BlkArgs {
   const uint4 *blk_hdr;      // per block {unique nodes, exclusive nodes, first shared slot, 0}
   const uint32_t *unodes;    // [n_blocks][max_u]: node | cmask << 29
   const uint4 *uent8;        // [n_blocks][max_u]: 8 LDS slot indices (16 bit each) per local node
-  const uint16_t *lidT;      // [3^dim][cstride]: local id (within its block) of each cell node
+  const uint16_t *lidT;      // [cstride][LID_ROW]: local id (within its block) of each cell node
   double *slots_sh;
 };
 
@@ -1203,7 +1203,18 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   uint32_t lids[HAS_U ? NV : 1];
   if (HAS_U) {
 #pragma unroll
-    for (int a = 0; a < NV; ++a) lids[a] = B.lidT[a * cs + cell];
+    for (int a = 0; a < NV; ++a) lids[a] = 0;
+    {
+      const uint4 *row = reinterpret_cast<const uint4 *>(B.lidT + (size_t)cell * LID_ROW);
+      uint32_t w[LID_ROW / 2];
+#pragma unroll
+      for (int k = 0; k < (NV + 7) / 8; ++k) {
+        const uint4 v = row[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int a = 0; a < NV; ++a) lids[a] = (a & 1) ? (w[a >> 1] >> 16) : (w[a >> 1] & 0xFFFFu);
+    }
   }
   double m_eta[ETA_LDS ? NETA_PL : 1];
   if (ETA_LDS) {
