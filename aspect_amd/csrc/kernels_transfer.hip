@@ -255,7 +255,7 @@ int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLe
   // the node-owner form only in rounding)
   // (AGMG_PROL_CELLS_MIN: developer/test knob for the switch-over size, read per call)
   const char *env = getenv("AGMG_PROL_CELLS_MIN");
-  const long min_cells = env ? atol(env) : 4096;
+  const long min_cells = env ? atol(env) : 131072;   // below: too few lanes, the node-owner form wins (r5: 19 vs 100 us)
   if (velocity && coarse.n_cells >= min_cells) {
     ProlCellArgs pc;
     pc.n_coarse_cells = coarse.n_cells;
