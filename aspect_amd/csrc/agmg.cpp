@@ -235,6 +235,7 @@ struct agmg_ctx {
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
     return use_ell && !dist() && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
   }
+  bool use_batched_setup = true;   // eigenvalue estimates of all levels in lock step (AGMG_NO_BATCHED_SETUP=1: one by one)
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
   // Chebyshev coefficient sequences of cheb_vmult / cheb_step as a program for the fused kernels
   void program_vmult(const Smoother &s, SmootherProgram &p) const;
@@ -271,6 +272,7 @@ struct agmg_ctx {
   int level_v_step(int which, int l);
   int vcycle(int which, double *dst, const double *src);
   int estimate_device(int which, int l);
+  int estimate_batched(const std::vector<std::pair<int, int>> &problems);
   int build_coarse(int which);
   int setup_smoothers();
 
@@ -468,12 +470,14 @@ int agmg_ctx::dots(const double *x, const std::vector<const double *> &ys, const
     const int nv = std::min(DOT_MAX_VECS, total - k0);
     VecPtrs vp;
     for (int k = 0; k < DOT_MAX_VECS; ++k) vp.p[k] = ys[k0 + std::min(k, nv - 1)];
-    CHECK(vec_multi_dot(stream, x, vp, nv, sp.n_dot, sp.seg1, sp.gap, dot_partials, dot_out_d + k0));
+    // one rank: the final reduction writes straight into the pinned (device-visible, coherent) host
+    // buffer: no copy kernel between the reduction and the host's wait
+    CHECK(vec_multi_dot(stream, x, vp, nv, sp.n_dot, sp.seg1, sp.gap, dot_partials, (dist() ? dot_out_d : dot_out_h) + k0));
   }
   if (dist() && comm.device_buffers) {
     if (comm.allreduce_sum(comm.user, dot_out_d, total, (void *)stream)) { set_error("all-reduce callback failed"); return -101; }
   }
-  AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+  if (dist()) AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, total * sizeof(double), hipMemcpyDeviceToHost, stream));
   CHECK(sync());
   if (dist() && !comm.device_buffers) {
     if (comm.allreduce_sum(comm.user, dot_out_h, total, nullptr)) { set_error("all-reduce callback failed"); return -101; }
@@ -975,6 +979,101 @@ int agmg_ctx::estimate_device(int which, int l) {
   return 0;
 }
 
+// The same estimates for several (operator, level) pairs at once, one rank: the CG iterations are
+// independent of each other, so every phase is enqueued for all of them before the host waits
+// once (2 waits per iteration in total instead of 3 per iteration and problem; the reductions
+// land directly in the pinned host buffer).  Same kernels, same order per problem as
+// estimate_device.
+int agmg_ctx::estimate_batched(const std::vector<std::pair<int, int>> &problems) {
+  struct St {
+    int which, l, max_it;
+    Span sp;
+    size_t n;
+    double range;
+    const double *dinv;
+    double *g, *h, *d, *Ad;
+    Lanczos lz;
+    double gh = 0, alpha = 0, beta = 0, res = 0;
+    bool active = true;
+  };
+  std::vector<St> P;
+  for (auto &pr : problems) {
+    St s;
+    s.which = pr.first; s.l = pr.second;
+    s.sp = span_of(s.which, s.l);
+    s.n = s.sp.n;
+    const bool coarse_lvl = s.l == 0;
+    Smoother &sm_ = sm[s.which][s.l];
+    sm_.degree = coarse_lvl ? opt.coarse_degree : opt.smoother_degree;
+    s.range = coarse_lvl ? opt.coarse_range : opt.smoothing_range;
+    s.max_it = coarse_lvl ? opt.coarse_eig_cg_n_iterations : opt.eig_cg_n_iterations;
+    s.dinv = s.which == 0 ? L[s.l].inv_diag_A : L[s.l].inv_diag_M;
+    s.g = mg_def[s.which][s.l]; s.h = mg_sol[s.which][s.l]; s.d = mg_tmp[s.which][s.l]; s.Ad = mg_t[s.which][s.l];
+    P.push_back(s);
+  }
+  if (2 * P.size() > 256) { set_error("estimate_batched: too many problems"); return -1; }
+  const double tol = 1e-10;
+  // start vectors, h = D^-1 g, (g.h, g.g)
+  auto phase_a = [&](St &s, int slot) -> int {
+    CHECK(vec_pointwise_scale(stream, s.h, 1.0, s.dinv, s.g, s.n));
+    VecPtrs vp;
+    for (int k = 0; k < DOT_MAX_VECS; ++k) vp.p[k] = k == 0 ? s.h : s.g;
+    return vec_multi_dot(stream, s.g, vp, 2, s.sp.n_dot, s.sp.seg1, s.sp.gap, dot_partials, dot_out_h + 2 * slot);   // (one stream: the partials buffer is free again)
+  };
+  for (size_t i = 0; i < P.size(); ++i) {
+    St &s = P[i];
+    CHECK(vec_fill_index_mod(stream, s.g, s.n, 11));
+    const size_t full = s.n / 11, rem = s.n % 11;
+    const double sum = (double)full * 55.0 + (double)(rem * (rem - 1) / 2);
+    CHECK(vec_shift(stream, s.g, -sum / (double)s.n, s.n));
+    CHECK(phase_a(s, (int)i));
+  }
+  CHECK(sync());
+  for (size_t i = 0; i < P.size(); ++i) {
+    P[i].gh = dot_out_h[2 * i];
+    P[i].res = std::sqrt(dot_out_h[2 * i + 1]);
+    P[i].active = P[i].res > tol && P[i].max_it > 0;
+  }
+  for (int it = 1;; ++it) {
+    bool any = false;
+    for (size_t i = 0; i < P.size(); ++i) {
+      St &s = P[i];
+      if (!s.active) continue;
+      any = true;
+      if (it > 1) CHECK(vec_sadd(stream, s.d, s.beta, 1.0, s.h, s.n));
+      else CHECK(vec_copy(stream, s.d, s.h, s.n));
+      EpiArgs e;
+      e.epi = EPI_STORE; e.dst = s.Ad; e.x = s.d;
+      CHECK(apply_level(s.which, s.l, L[s.l].coeff, s.d, e));
+      VecPtrs vp;
+      for (int k = 0; k < DOT_MAX_VECS; ++k) vp.p[k] = s.Ad;
+      CHECK(vec_multi_dot(stream, s.d, vp, 1, s.sp.n_dot, s.sp.seg1, s.sp.gap, dot_partials, dot_out_h + 2 * i));
+    }
+    if (!any) break;
+    CHECK(sync());
+    for (size_t i = 0; i < P.size(); ++i) {
+      St &s = P[i];
+      if (!s.active) continue;
+      s.alpha = s.gh / dot_out_h[2 * i];
+      CHECK(vec_axpy(stream, s.g, -s.alpha, s.Ad, s.n));
+      CHECK(phase_a(s, (int)i));
+    }
+    CHECK(sync());
+    for (size_t i = 0; i < P.size(); ++i) {
+      St &s = P[i];
+      if (!s.active) continue;
+      const double gh_new = dot_out_h[2 * i];
+      s.res = std::sqrt(dot_out_h[2 * i + 1]);
+      s.lz.push(it, s.alpha, s.beta);
+      if (s.res <= tol || it >= s.max_it || !std::isfinite(s.res)) { s.active = false; continue; }
+      s.beta = gh_new / s.gh;
+      s.gh = gh_new;
+    }
+  }
+  for (St &s : P) finish_smoother(sm[s.which][s.l], s.lz, s.range);
+  return 0;
+}
+
 // dense level-0 operator (by columns) + host eigenvalue estimate
 int agmg_ctx::build_coarse(int which) {
   CoarseOp &co = coarse[which];
@@ -982,18 +1081,38 @@ int agmg_ctx::build_coarse(int which) {
   co.n = n;
   co.A.assign((size_t)n * n, 0.0);
   co.dinv.resize(n);
-  double *x = mg_sol[which][0], *y = mg_t[which][0];
-  CHECK(vec_set(stream, x, 0.0, n));
-  std::vector<double> col(n);
-  const double one = 1.0, zero = 0.0;
-  for (int j = 0; j < n; ++j) {
-    AGMG_HIP_CHECK(hipMemcpyAsync(x + j, &one, sizeof(double), hipMemcpyHostToDevice, stream));
-    EpiArgs e;
-    e.epi = EPI_STORE; e.dst = y; e.x = x;
-    CHECK(apply_level(which, 0, L[0].coeff, x, e));
-    CHECK(d2h(col.data(), y, n));
-    AGMG_HIP_CHECK(hipMemcpyAsync(x + j, &zero, sizeof(double), hipMemcpyHostToDevice, stream));
-    for (int i = 0; i < n; ++i) co.A[(size_t)i * n + j] = col[i];
+  if (n <= 4096) {
+    // all columns back to back on the stream (identity in, operator columns out), one copy back
+    std::vector<double> eye((size_t)n * n, 0.0), cols((size_t)n * n);
+    for (int j = 0; j < n; ++j) eye[(size_t)j * n + j] = 1.0;
+    double *X = nullptr, *Y = nullptr;
+    CHECK(dalloc(&X, eye.size()));
+    int rc = dalloc(&Y, eye.size());
+    if (!rc) rc = h2d(X, eye.data(), eye.size());
+    for (int j = 0; j < n && !rc; ++j) {
+      EpiArgs e;
+      e.epi = EPI_STORE; e.dst = Y + (size_t)j * n; e.x = X + (size_t)j * n;
+      rc = apply_level(which, 0, L[0].coeff, X + (size_t)j * n, e);
+    }
+    if (!rc) rc = d2h(cols.data(), Y, cols.size());
+    dfree(X); dfree(Y);
+    if (rc) return rc;
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) co.A[(size_t)i * n + j] = cols[(size_t)j * n + i];
+  } else {
+    double *x = mg_sol[which][0], *y = mg_t[which][0];
+    CHECK(vec_set(stream, x, 0.0, n));
+    std::vector<double> col(n);
+    const double one = 1.0, zero = 0.0;
+    for (int j = 0; j < n; ++j) {
+      AGMG_HIP_CHECK(hipMemcpyAsync(x + j, &one, sizeof(double), hipMemcpyHostToDevice, stream));
+      EpiArgs e;
+      e.epi = EPI_STORE; e.dst = y; e.x = x;
+      CHECK(apply_level(which, 0, L[0].coeff, x, e));
+      CHECK(d2h(col.data(), y, n));
+      AGMG_HIP_CHECK(hipMemcpyAsync(x + j, &zero, sizeof(double), hipMemcpyHostToDevice, stream));
+      for (int i = 0; i < n; ++i) co.A[(size_t)i * n + j] = col[i];
+    }
   }
   CHECK(d2h(co.dinv.data(), which == 0 ? L[0].inv_diag_A : L[0].inv_diag_M, n));
   // host CG for the eigenvalue estimate
@@ -1044,11 +1163,14 @@ int agmg_ctx::setup_smoothers() {
   CHECK(ensure_workspace());
   CHECK(ensure_transfers());
   CHECK(ensure_mg_vectors());
+  std::vector<std::pair<int, int>> batch;
   for (int w = 0; w < 2; ++w)
     for (int l = 0; l < nl(); ++l) {
       if (l == 0 && opt.coarse_on_host && !dist()) CHECK(build_coarse(w));
+      else if (!dist() && use_batched_setup) batch.emplace_back(w, l);
       else CHECK(estimate_device(w, l));
     }
+  if (!batch.empty()) CHECK(estimate_batched(batch));
   smoothers_ready = true;
   return 0;
 }
@@ -1544,6 +1666,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_NO_BATCHED_SETUP")) c->use_batched_setup = atoi(e) == 0;
   c->L.resize(opt->n_levels);
   c->H.resize(opt->n_levels);
   for (int w = 0; w < 2; ++w) c->send_nodes_h[w].resize(opt->n_levels);
@@ -1820,19 +1943,36 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   if (d->n_q_viscosity != 1 && d->n_q_viscosity != NQ) { set_error("n_q_viscosity must be 1 or 3^dim"); return -1; }
   if (!d->viscosity) { set_error("viscosity table missing"); return -1; }
   const size_t cs = lv.cstride;
-  std::vector<double> T((size_t)d->n_q_viscosity * cs, 1.0);
-  for (int cell = 0; cell < lv.n_cells; ++cell)
-    for (int q = 0; q < d->n_q_viscosity; ++q) {
-      const double v = d->viscosity[(size_t)cell * d->n_q_viscosity + q];
-      if (!(v > 0)) { set_error("viscosity must be positive"); return -1; }
-      T[(size_t)q * cs + cell] = v;
+  {
+    // the table crosses PCIe as it is ([cell][q]); transposition to [q][cstride] and the positivity
+    // check run on the device (a host loop over 5.7e7 strided entries cost 0.6 s at r7)
+    const size_t n_in = (size_t)lv.n_cells * d->n_q_viscosity, n_out = (size_t)d->n_q_viscosity * cs;
+    double *raw = nullptr, *etaT = nullptr;
+    int *bad = nullptr;
+    CHECK(c->dalloc(&raw, n_in));
+    int rc = c->dalloc(&etaT, n_out);
+    if (!rc) rc = c->dalloc(&bad, 1);
+    int bad_h = 0;
+    if (!rc && hipMemcpyAsync(raw, d->viscosity, n_in * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -3;
+    if (!rc && hipMemsetAsync(bad, 0, sizeof(int), c->stream) != hipSuccess) rc = -3;
+    if (!rc) rc = vec_transpose_table(c->stream, etaT, raw, lv.n_cells, d->n_q_viscosity, cs, bad);
+    if (!rc && hipMemcpyAsync(&bad_h, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -3;
+    if (!rc) rc = c->sync();
+    c->dfree(raw); c->dfree(bad);
+    if (rc || bad_h) {
+      c->dfree(etaT);
+      if (bad_h) { set_error("viscosity must be positive"); return -1; }
+      if (rc == -3) set_error("HIP error while uploading the viscosity table");
+      return rc;
     }
-  c->dfree(cd.etaT);
-  CHECK(c->upload(&cd.etaT, T));
+    c->dfree(cd.etaT);
+    cd.etaT = etaT;
+  }
+  const size_t T_size = (size_t)d->n_q_viscosity * cs;
   cd.nqv = d->n_q_viscosity;
   cd.lambda = d->pressure_scaling;
   cd.is_compressible = d->is_compressible;
-  cd.bytes = T.size() * 8;
+  cd.bytes = T_size * 8;
   c->dfree(cd.nw_strain); c->dfree(cd.nw_dEde); c->dfree(cd.nw_dEdp);
   cd.newton = false;
   if (d->enable_newton_derivatives) {

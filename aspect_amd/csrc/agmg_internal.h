@@ -251,6 +251,8 @@ int vec_lincomb(hipStream_t s, double *dst, double a, const double *x, double b,
 int vec_pointwise_scale(hipStream_t s, double *dst, double f, const double *d, const double *b, size_t n);  // dst = f*d*b
 int vec_zero_constrained(hipStream_t s, double *x, const uint8_t *cmask, int n_nodes, int ncomp);
 int vec_fill_index_mod(hipStream_t s, double *x, size_t n, int mod);
+// dst[q][cstride] = src[cell][nq] (cells >= n_cells: 1.0); *bad (device int) is set where !(value > 0)
+int vec_transpose_table(hipStream_t s, double *dst, const double *src, size_t n_cells, int nq, size_t cstride, int *bad);
 // x[node*nc + c] = (gid[node]*nc + c) % mod
 int vec_fill_gid_mod(hipStream_t s, double *x, const uint32_t *gid, int n_nodes, int nc, int mod);
 // out[k*nc + c] = x[nodes[k]*nc + c]

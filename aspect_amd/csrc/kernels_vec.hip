@@ -150,6 +150,47 @@ int vec_zero_constrained(hipStream_t s, double *x, const uint8_t *cmask, int n_n
   LAUNCH_VEC(k_zero_constrained, n, x, cmask, n, ncomp);
 }
 int vec_shift(hipStream_t s, double *x, double a, size_t n) { LAUNCH_VEC(k_shift, n, x, a, n); }
+// coefficient tables arrive [cell][q] (the caller's flattened Table) and live [q][cstride]: a tile
+// through LDS keeps both sides coalesced
+__global__ void __launch_bounds__(256) k_transpose_table(double *dst, const double *src, size_t n_cells, int nq, size_t cs, int *bad) {
+  __shared__ double tile[64][33];
+  const size_t cell0 = (size_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  bool any_bad = false;
+  for (int q0 = 0; q0 < nq; q0 += 32) {
+    // read: rows = cells, contiguous in q
+    for (int r = ty; r < 64; r += 8) {
+      const size_t cell = cell0 + r;
+      const int q = q0 + tx;
+      double v = 1.0;
+      if (cell < n_cells && q < nq) {
+        v = src[cell * nq + q];
+        if (!(v > 0)) any_bad = true;
+      }
+      tile[r][tx] = v;
+    }
+    __syncthreads();
+    // write: rows = q, contiguous in cells
+    for (int qq = ty; qq < 32; qq += 8) {
+      const int q = q0 + qq;
+      if (q < nq) {
+        for (int half = 0; half < 2; ++half) {
+          const size_t cell = cell0 + tx + 32 * half;
+          if (cell < cs) dst[(size_t)q * cs + cell] = tile[tx + 32 * half][qq];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (any_bad) atomicOr(bad, 1);
+}
+int vec_transpose_table(hipStream_t s, double *dst, const double *src, size_t n_cells, int nq, size_t cstride, int *bad) {
+  if (cstride == 0) return 0;
+  hipLaunchKernelGGL(k_transpose_table, dim3((unsigned)((cstride + 63) / 64)), dim3(256), 0, s, dst, src, n_cells, nq, cstride, bad);
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int vec_fill_index_mod(hipStream_t s, double *x, size_t n, int mod) { LAUNCH_VEC(k_fill_mod, n, x, n, mod); }
 
 int vec_fill_gid_mod(hipStream_t s, double *x, const uint32_t *gid, int n_nodes, int nc, int mod) {
