@@ -1237,7 +1237,11 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
     double sv[MAXU_PT][DIM];
 #pragma unroll
     for (int i = 0; i < MAXU_PT; ++i) {   // all loads first
-      m_node[i] = l_unodes[min((int)threadIdx.x + i * NT, U - 1)];
+      // only this wave's own table entries have provably landed (no barrier yet): entry t, which the
+      // host pads with node 0 up to max_u, never another wave's entry U - 1 -- that one may still be
+      // whatever an earlier kernel left in this LDS and would send the gather to a wild address
+      const int t = (int)threadIdx.x + i * NT;
+      m_node[i] = t < max_u ? l_unodes[t] : 0u;
       const double *sp = A.src_u + (size_t)(m_node[i] & NODE_MASK) * DIM;
 #pragma unroll
       for (int cc = 0; cc < DIM; ++cc) sv[i][cc] = sp[cc];
