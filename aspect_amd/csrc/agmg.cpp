@@ -716,13 +716,13 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
   CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
   CHECK(exchange(m));
   CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_GHOST));
-  CHECK(launch_pull_p(stream, lv, slots_p, lv.dim, ep, PH_GHOST));
+  CHECK(launch_pull_p(stream, lv, slots_p, 1, ep, PH_GHOST));
   m.clear();
   add_compress(m, lv.xv, lv.xv.nc);
   add_compress(m, lv.xp, 1);
   CHECK(exchange(m));
   CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_OWNED));
-  CHECK(launch_pull_p(stream, lv, slots_p, lv.dim, ep, PH_OWNED));
+  CHECK(launch_pull_p(stream, lv, slots_p, 1, ep, PH_OWNED));
   if (!faces.global_active) return 0;
   // boundary-face loop (matrix_free_operators.cc:343-353): the sums of the local faces go to the owned
   // rows directly; those of ghost rows travel to their owners in one more compress step

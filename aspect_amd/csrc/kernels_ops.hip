@@ -80,6 +80,23 @@ __host__ __device__ constexpr double dcol(int q, int i) {  // collocation deriva
                 : (q == 1 ? (i == 0 ? -0.5 : (i == 1 ? 0.0 : 0.5)) : (i == 0 ? 0.5 : (i == 1 ? -2.0 : 1.5)));
 }
 
+// Stokes pressure rows: the DIM lanes of a cell each hold the divergence contribution of their
+// velocity component; they are summed across the lanes (fixed order c = 0, 1, 2) so that one value
+// per (cell, pressure node) goes to the slots instead of DIM
+template <int DIM, int NP>
+__device__ __forceinline__ void sum_over_components(double *pout) {
+#pragma unroll
+  for (int b = 0; b < NP; ++b) {
+    const double a1 = __shfl_down(pout[b], 1, 64);
+    if (DIM == 3) {
+      const double a2 = __shfl_down(pout[b], 2, 64);
+      pout[b] = (pout[b] + a1) + a2;
+    } else {
+      pout[b] = pout[b] + a1;
+    }
+  }
+}
+
 struct CellArgs {
   int n_cells, cstride;
   const uint32_t *cnvT, *cnpT;
@@ -578,6 +595,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, NEWTON ? 1 : AGMG_CELLS_
   double G[NV], pout[NP];
   double u[NV];
   cell_compute<DIM, OP, COMP, PERQ, false, true, GEN, NEWTON>(A, cell, c, j, lane, xbuf[wave], G, pout, nullptr, u);
+  if (OP == KOP_STOKES) sum_over_components<DIM, NP>(pout);
   if (valid) {
 #pragma unroll
     for (int a = 0; a < NV; ++a)
@@ -585,9 +603,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, NEWTON ? 1 : AGMG_CELLS_
       if (G[a] == 12345.678)
 #endif
       A.slots_u[((size_t)a * cs + cell) * DIM + c] = G[a];
-    if (OP == KOP_STOKES) {
+    if (OP == KOP_STOKES && c == 0) {
 #pragma unroll
-      for (int b = 0; b < NP; ++b) A.slots_p[((size_t)b * cs + cell) * DIM + c] = pout[b];
+      for (int b = 0; b < NP; ++b) A.slots_p[(size_t)b * cs + cell] = pout[b];
     }
   }
 }
@@ -1279,9 +1297,10 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
     double *my = wtile + lane;
 #pragma unroll
     for (int a = 0; a < NV; ++a) my[a * BLK_SLOT_ROW] = G[a];
-    if (OP == KOP_STOKES && lane_ok && cell_l < A.n_cells) {
+    if (OP == KOP_STOKES) sum_over_components<DIM, NP>(pout);
+    if (OP == KOP_STOKES && c == 0 && lane_ok && cell_l < A.n_cells) {
 #pragma unroll
-      for (int bb = 0; bb < NP; ++bb) A.slots_p[((size_t)bb * cs + cell) * DIM + c] = pout[bb];
+      for (int bb = 0; bb < NP; ++bb) A.slots_p[(size_t)bb * cs + cell] = pout[bb];
     }
   }
   AGMG_STAMP(3);
@@ -1344,7 +1363,7 @@ __global__ void __launch_bounds__(256) k_fix(const FixArgs F) { fix_body<NC>(F, 
 template <int DIM>
 __global__ void __launch_bounds__(256) k_fix_pull(const FixArgs F, const PullArgs P, const unsigned n_fix_blocks) {
   if (blockIdx.x < n_fix_blocks) fix_body<DIM>(F, blockIdx.x);
-  else pull_body<1, DIM>(P, blockIdx.x - n_fix_blocks);
+  else pull_body<1, 1>(P, blockIdx.x - n_fix_blocks);
 }
 
 // StokesOperator::local_apply_boundary_face (matrix_free_operators.cc:294-333), node-owner form: one
@@ -1710,7 +1729,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
     }
     const int rc = launch_pull_v(s, L, slots_u, eu, phase);
     if (rc || !ep) return rc;
-    return launch_pull_p(s, L, slots_p, L.dim, *ep, PH_ALL);
+    return launch_pull_p(s, L, slots_p, 1, *ep, PH_ALL);
   }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
@@ -1766,7 +1785,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
 #endif
   if (phase == PH_GHOST) return fix(bt.n_shared_owned, bt.n_shared - bt.n_shared_owned, true);
   if (!ep) return fix(0, bt.n_shared, false);
-  if (bt.n_shared <= 0) return launch_pull_p(s, L, slots_p, L.dim, *ep, PH_ALL);
+  if (bt.n_shared <= 0) return launch_pull_p(s, L, slots_p, 1, *ep, PH_ALL);
   {  // one launch for the velocity fix-up and the pressure pull
     FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, 0, bt.n_shared, 0xFFFFFFFFu, nullptr, nullptr, L.n_owned_v, eu};
     PullArgs p{L.pull_ptr_p, L.pull_list_p, slots_p, L.cmask_p, 0, L.n_nodes_p, 0xFFFFFFFFu, nullptr, nullptr, *ep};
