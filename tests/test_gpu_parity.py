@@ -32,6 +32,9 @@ def rand_vec(n, seed, level, zero_constrained=True, with_p=0):
 
 PROBLEMS = {
     "nsinker_r2_harmonic": lambda: cases.nsinker_box(2, n_sinkers=4, ratio=1e4),
+    # several blocks with cell-constant viscosity and no-slip walls (the block kernels' <cell-constant>
+    # variants with a fix-up pass; r2 is a single block)
+    "nsinker_r3_harmonic": lambda: cases.nsinker_box(3, n_sinkers=4, ratio=1e4),
     "nsinker_r2_perq": lambda: cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE),
     "box3d_r2_freeslip": lambda: cases.convection_box(3, 2),
     "box3d_r3_freeslip": lambda: cases.convection_box(3, 3),
@@ -403,6 +406,23 @@ def test_free_surface_face_term(dim, refinement, kw, hip_lib, oracle_lib):
     res_o = np.linalg.norm(rhs - o.vmult(capi.OP_STOKES, xo))
     assert res_g <= max(1.05 * rg.solver_tolerance, 10.0 * res_o)
     assert relerr(xg[:nu], xo[:nu]) < 1e-4
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("case", ["sinker", "box"])
+def test_single_level_operator_benchmark_path(case, hip_lib, oracle_lib):
+    """agmg_bench_vmult on a single-level context whose first kernel launches are the Stokes operator
+    (tools/prof_vmult.py's path; a fresh process once sent the block kernel's gather to a wild address
+    here), followed by the same operator through agmg_vmult against the oracle."""
+    p = cases.nsinker_box(4, n_sinkers=4, ratio=1e4) if case == "sinker" else cases.convection_box(3, 4)
+    p.build_single_level()
+    g = capi.Solver(hip_lib, p, single_level=True)
+    assert g.bench_vmult(capi.OP_STOKES, capi.ACTIVE, 3) > 0
+    assert g.bench_vmult(capi.OP_A, capi.ACTIVE, 3) > 0
+    assert g.bench_vmult(capi.OP_MASS, 0, 3) > 0
+    o = capi.Solver(oracle_lib, p, single_level=True)
+    src = rand_vec(g.size(capi.OP_STOKES), 5, p.hier.finest)
+    assert relerr(g.vmult(capi.OP_STOKES, src), o.vmult(capi.OP_STOKES, src)) < RTOL
     g.close(); o.close()
 
 
