@@ -93,7 +93,7 @@ SYMBOLS = [
     "default_options", "last_error", "create", "destroy", "set_communicator",
     "rccl_get_unique_id", "set_communicator_rccl", "set_level", "set_coefficients",
     "set_free_surface_faces",
-    "compute_diagonals", "vmult", "vmult_device", "get_inverse_diagonal", "prolongate_add",
+    "compute_diagonals", "vmult", "vmult_device", "vmult_device_noalloc", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
     "solve", "bench_vmult", "get_cell_data_memory_consumption",
     "get_mg_transfer_memory_consumption", "get_constraint_memory_consumption",
@@ -145,6 +145,7 @@ class Library:
         self.compute_diagonals = fn("compute_diagonals", C.c_int, [vp])
         self.vmult = fn("vmult", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         self.vmult_device = fn("vmult_device", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
+        self.vmult_device_noalloc = fn("vmult_device_noalloc", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
         self.vmult_dense = fn("vmult_dense", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         self.get_inverse_diagonal = fn("get_inverse_diagonal", C.c_int, [vp, C.c_int, C.c_int, c_dp])
         self.prolongate_add = fn("prolongate_add", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])

@@ -230,6 +230,8 @@ struct agmg_ctx {
     return sync();
   }
 
+  // doubles of slots_u the block path of a level writes beyond the cell slots (partial sums of shared nodes)
+  size_t scratch_u_need(const DeviceLevel &lv) const { return lv.bt.built ? lv.bt.n_shared_slots * (size_t)lv.dim : 0; }
   bool use_blocks = true;
   bool use_ell = true;     // assembled rows for the Q1 mass operator (AGMG_NO_ELL=1: matrix-free cell kernel + pull)
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
@@ -242,6 +244,11 @@ struct agmg_ctx {
   void program_step(const Smoother &s, SmootherProgram &p) const;
   bool fused_mass(int l) const { return use_fused && L[l].mass_fusable; }
   void free_level(DeviceLevel &l);
+  void free_coeff(CoeffData &cd) {
+    dfree(cd.etaT); dfree(cd.nw_strain); dfree(cd.nw_dEde); dfree(cd.nw_dEdp);
+    dfree(cd.dil_lhs); dfree(cd.dil_de); dfree(cd.dil_dp); dfree(cd.ell_val);
+    cd = CoeffData();
+  }
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                          const std::vector<uint32_t> &send_nodes);
   int ensure_workspace();
@@ -1364,8 +1371,9 @@ struct Hessenberg {  // Givens-rotated least-squares state shared by GMRES and F
       h[i + 1] = -si[i] * t + ci[i] * h[i + 1];
     }
     const double r = std::hypot(h[j], h[j + 1]);
-    ci[j] = h[j] / r;
-    si[j] = h[j + 1] / r;
+    // r == 0: the Krylov space is exhausted (happy breakdown); identity rotation, zero pivot guarded in solve()
+    ci[j] = r > 0.0 ? h[j] / r : 1.0;
+    si[j] = r > 0.0 ? h[j + 1] / r : 0.0;
     h[j] = r;
     gamma[j + 1] = -si[j] * gamma[j];
     gamma[j] *= ci[j];
@@ -1377,7 +1385,7 @@ struct Hessenberg {  // Givens-rotated least-squares state shared by GMRES and F
     for (int i = dim - 1; i >= 0; --i) {
       double s = gamma[i];
       for (int k = i + 1; k < dim; ++k) s -= H[i][k] * y[k];
-      y[i] = s / H[i][i];
+      y[i] = H[i][i] != 0.0 ? s / H[i][i] : 0.0;
     }
     return y;
   }
@@ -1656,11 +1664,20 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (opt->degree_v != 2) { set_error("only Stokes velocity polynomial degree 2 (Q2-Q1) is built"); return nullptr; }
   if (opt->n_levels < 1) { set_error("n_levels must be >= 1"); return nullptr; }
   if (opt->world_size < 1 || opt->rank < 0 || opt->rank >= opt->world_size) { set_error("bad world_size / rank"); return nullptr; }
+  // (the fused multi-dot returns at most 256 scalars per call: restart + 2 basis vectors)
+  if (opt->gmres_restart < 1 || opt->gmres_restart > 250) { set_error("gmres_restart must be in [1, 250]"); return nullptr; }
+  if (opt->idr_s < 1 || opt->idr_s > 64) { set_error("idr_s must be in [1, 64]"); return nullptr; }
+  if (opt->n_cheap_steps < 0 || opt->n_expensive_steps < 0) { set_error("step counts must be >= 0"); return nullptr; }
+  if (opt->smoother_degree < 1 || opt->coarse_degree < 1 || opt->schur_smoother_steps < 1 ||
+      opt->eig_cg_n_iterations < 1 || opt->coarse_eig_cg_n_iterations < 1) {
+    set_error("smoother degrees, steps and eigenvalue iterations must be >= 1"); return nullptr;
+  }
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: this library has no CPU path"); return nullptr; }
   if (opt->device < 0 || opt->device >= ndev) { set_error("bad device ordinal"); return nullptr; }
   if (hipSetDevice(opt->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+  if (static_scratch_init(opt->device)) return nullptr;   // device address of this GPU's static scratch
   auto *c = new agmg_ctx();
   c->opt = *opt;
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
@@ -1702,9 +1719,7 @@ void agmg_destroy(agmg_ctx *c) {
   (void)hipSetDevice(c->opt.device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &l : c->L) c->free_level(l);
-  c->dfree(c->active.ell_val);
-  c->dfree(c->active.etaT); c->dfree(c->active.nw_strain); c->dfree(c->active.nw_dEde); c->dfree(c->active.nw_dEdp);
-  c->dfree(c->active.dil_lhs); c->dfree(c->active.dil_de); c->dfree(c->active.dil_dp);
+  c->free_coeff(c->active);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
   for (auto &p : c->bicg_pool) c->dfree(p);
   c->free_faces();
@@ -1756,7 +1771,10 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   }
   DeviceLevel &lv = c->L[level];
   c->free_level(lv);
-  if (level == c->nl() - 1) c->free_faces();   // face tables refer to the cells of the active mesh
+  if (level == c->nl() - 1) {   // face tables and the active coefficients refer to the cells of the active mesh
+    c->free_faces();
+    c->free_coeff(c->active);
+  }
   HostLevel &hl = c->H[level];
   lv.dim = dim;
   lv.n_cells = d->n_cells; lv.n_nodes_v = d->n_nodes_v; lv.n_nodes_p = d->n_nodes_p;
@@ -2163,11 +2181,8 @@ static int vmult_sizes(agmg_ctx *c, int which, int level, size_t *n) {
   return 0;
 }
 
-int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const double *src) {
-  if (!c) { set_error("null context"); return -1; }
-  size_t n;
-  CHECK(vmult_sizes(c, which, level, &n));
-  CHECK(c->ensure_workspace());
+// the operator application itself, on the context's current slot buffers (slots_u, slots_p)
+static int vmult_device_impl(agmg_ctx *c, int which, int level, double *dst, const double *src) {
   const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
   const DeviceLevel &lv = c->L[l];
   const CoeffData &cd = level == AGMG_ACTIVE ? c->active_coeff() : lv.coeff;
@@ -2197,6 +2212,53 @@ int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const doub
       return vec_set(c->stream, dst + nu, 0.0, np);
     }
   }
+}
+
+int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const double *src) {
+  if (!c) { set_error("null context"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  size_t n;
+  CHECK(vmult_sizes(c, which, level, &n));
+  CHECK(c->ensure_workspace());
+  return vmult_device_impl(c, which, level, dst, src);
+}
+
+// agmg_vmult_device for callers that may not allocate (HIP graph capture, serving loops): the slot
+// buffers come out of this GPU's static scratch (scratch.hip) instead of the context's workspace.
+// No hipMalloc / hipFree / allocating routine on this path.  The scratch keeps the previous call's
+// contents: every kernel on this path writes a slot before any kernel reads it (nothing has to start
+// at zero).  Calls that overlap on one GPU share the array and race.
+int agmg_vmult_device_noalloc(agmg_ctx *c, int which, int level, double *dst, const double *src) {
+  if (!c) { set_error("null context"); return -1; }
+  if (!dst || !src) { set_error("null vector"); return -1; }
+  if (c->dist()) { set_error("agmg_vmult_device_noalloc: one-rank contexts only (the ghost exchange stages through buffers it allocates)"); return -2; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  size_t n;
+  CHECK(vmult_sizes(c, which, level, &n));
+  double *base = static_cast<double *>(static_scratch_ptr(c->opt.device));
+  if (!base) { set_error("static scratch not initialised on this device"); return -100; }
+  const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
+  const DeviceLevel &lv = c->L[l];
+  if (!lv.set) { set_error("level not set"); return -1; }
+  const int dim = lv.dim, NV = ipow(3, dim), NP = ipow(2, dim);
+  // doubles the kernels of this operator write to the slot buffers (the largest path they may take)
+  size_t su = 0, sp = 0;
+  if (which != AGMG_OP_MASS) su = std::max((size_t)NV * lv.cstride * dim, c->scratch_u_need(lv));
+  if (which == AGMG_OP_STOKES || which == AGMG_OP_MASS) sp = (size_t)NP * lv.cstride * dim;
+  su = (su + 31) / 32 * 32;   // keep the second buffer 256-byte aligned
+  const size_t need = (su + sp) * sizeof(double);
+  if (need > STATIC_SCRATCH_BYTES) {
+    set_error("agmg_vmult_device_noalloc: this level needs " + std::to_string(need) + " bytes of scratch, the static scratch holds " +
+              std::to_string(STATIC_SCRATCH_BYTES) + " (use agmg_vmult_device)");
+    return -3;
+  }
+  double *const save_u = c->slots_u, *const save_p = c->slots_p;
+  c->slots_u = base;
+  c->slots_p = base + su;
+  const int rc = vmult_device_impl(c, which, level, dst, src);
+  c->slots_u = save_u;
+  c->slots_p = save_p;
+  return rc;
 }
 
 int agmg_vmult(agmg_ctx *c, int which, int level, double *dst, const double *src) {

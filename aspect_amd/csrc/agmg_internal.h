@@ -241,6 +241,11 @@ int rccl_unique_id(uint8_t id[128]);
 int rccl_comm_create(const uint8_t id[128], int rank, int size, agmg_comm *out, void **state);
 void rccl_comm_destroy(void *state);
 
+// ---- static device scratch (scratch.hip): for the entry point that allocates nothing ----
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)64 << 20;   // per GPU, held until the process ends
+int static_scratch_init(int device);      // once per device, that device current (agmg_create)
+void *static_scratch_ptr(int device);     // device address of this GPU's copy, or nullptr
+
 // ---- vector kernels (kernels_vec.hip) ----
 int vec_set(hipStream_t s, double *x, double v, size_t n);
 int vec_copy(hipStream_t s, double *dst, const double *src, size_t n);

@@ -266,6 +266,17 @@ int agmg_vmult(agmg_ctx *ctx, int which, int level, double *dst, const double *s
 /* same on device pointers, asynchronous on the context's stream */
 int agmg_vmult_device(agmg_ctx *ctx, int which, int level, double *dst, const double *src);
 
+/* agmg_vmult_device for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart
+ * in the reference.  Same arguments and results as agmg_vmult_device; the slot /
+ * partial-sum buffers of the kernels live in a static 64 MiB device array of the
+ * library (one copy per GPU, held until the process ends) instead of the
+ * context's workspace, and no hipMalloc, hipFree or allocating routine is called.
+ * Levels whose kernels need more scratch than that are rejected (status -3, the
+ * message names both sizes); one-rank contexts only (-2 otherwise).  All calls on
+ * one GPU share the array: calls that overlap on one GPU race. */
+int agmg_vmult_device_noalloc(agmg_ctx *ctx, int which, int level, double *dst, const double *src);
+
 /* get_matrix_diagonal_inverse() of the level A / mass operators, copied to host */
 int agmg_get_inverse_diagonal(agmg_ctx *ctx, int which, int level, double *dst);
 

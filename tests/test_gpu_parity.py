@@ -479,3 +479,37 @@ def test_reference_style_interface(hip_lib, oracle_lib):
     assert h.get_cell_data_memory_consumption() > 0 and h.get_dof_handler_memory_consumption() > 0
     assert h.get_mg_transfer_memory_consumption() > 0 and h.get_constraint_memory_consumption() > 0
     o.close()
+
+
+def test_set_level_again_resets_active_coefficients(hip_lib, oracle_lib):
+    """setup_dofs() after a mesh change: re-running agmg_set_level on every level (other cell counts)
+    must drop the ACTIVE coefficient tables of the old mesh; a caller that then sets level coefficients
+    only gets the finest level's tables for the active operators (documented aliasing)."""
+    pa = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE).build()
+    pb = cases.nsinker_box(2, n_sinkers=4, ratio=1e4)
+    pb.reps = [2, 1, 2]
+    pb.build()
+    assert pa.hier.n_levels == pb.hier.n_levels and pa.hier.finest.n_cells != pb.hier.finest.n_cells
+    g = capi.Solver(hip_lib, pa)                      # active tables: per-q, old cell count
+    g.problem = pb
+    for l, lev in enumerate(pb.hier.levels):
+        g._set_level(l, lev)
+    for l in range(pb.hier.n_levels):                 # level coefficients only
+        g._set_coeff(l, pb.eta_levels[l])
+    o = capi.Solver(oracle_lib, pb)
+    fin = pb.hier.finest
+    for which in (capi.OP_STOKES, capi.OP_A, capi.OP_BT):
+        src = rand_vec(fin.n_dofs_v + (fin.n_dofs_p if which != capi.OP_A else 0), 9 + which, fin)
+        assert relerr(g.vmult(which, src), o.vmult(which, src)) < RTOL, which
+    g.close(); o.close()
+
+
+def test_option_validation(hip_lib):
+    import ctypes as C
+    for field, value, word in (("gmres_restart", 0, b"gmres_restart"), ("gmres_restart", 300, b"gmres_restart"),
+                               ("idr_s", 0, b"idr_s"), ("n_cheap_steps", -1, b"step counts")):
+        opt = capi.Options()
+        hip_lib.default_options(C.byref(opt))
+        setattr(opt, field, value)
+        assert not hip_lib.create(C.byref(opt))
+        assert word in hip_lib.last_error()

@@ -1,0 +1,69 @@
+"""agmg_vmult_device_noalloc (include/agmg.h): the entry point that allocates nothing.  Its slot /
+partial-sum buffers come out of the library's static device scratch; results must equal
+agmg_vmult_device's (same kernels, same order of sums: bit for bit) on two calls in a row, the second
+on a smaller input, and levels beyond the scratch are rejected with a clear error."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from aspect_amd import capi, cases
+from hipmem import DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_vmult(fn, s, which, level, src_h):
+    src = DeviceArray(src_h.size).upload(src_h)
+    dst = DeviceArray(src_h.size).fill_bytes(0xFF)      # NaN pattern: every entry must be written
+    s._check(fn(s.ctx, which, level, dst.ptr, src.ptr))
+    out = dst.download()                                  # hipDeviceSynchronize drains the library's stream
+    src.free(); dst.free()
+    return out
+
+
+def test_noalloc_matches_vmult_device(hip_lib):
+    big = cases.nsinker_box(3, n_sinkers=4, ratio=1e4).build()     # several blocks: shared-node partial sums in scratch
+    small = cases.convection_box(3, 2).build()                      # per-q viscosity, one block
+    sb, ss = capi.Solver(hip_lib, big), capi.Solver(hip_lib, small)
+    try:
+        rng = np.random.Generator(np.random.PCG64(2025))
+        # two calls in a row on one GPU, the second with a smaller input (the scratch keeps the first call's contents)
+        for s, levels in ((sb, (capi.ACTIVE, 3, 2)), (ss, (capi.ACTIVE, 1))):
+            for level in levels:
+                for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT, capi.OP_MASS):
+                    src = rng.uniform(-1, 1, s.size(which, level))
+                    ref = _device_vmult(hip_lib.vmult_device, s, which, level, src)
+                    got = _device_vmult(hip_lib.vmult_device_noalloc, s, which, level, src)
+                    assert np.all(np.isfinite(ref))
+                    assert np.array_equal(got, ref), (which, level, np.abs(got - ref).max())
+        # and again big after small
+        src = rng.uniform(-1, 1, sb.size(capi.OP_STOKES))
+        assert np.array_equal(_device_vmult(hip_lib.vmult_device_noalloc, sb, capi.OP_STOKES, capi.ACTIVE, src),
+                              _device_vmult(hip_lib.vmult_device, sb, capi.OP_STOKES, capi.ACTIVE, src))
+    finally:
+        sb.close()
+        ss.close()
+
+
+def test_noalloc_rejects_levels_beyond_the_scratch(hip_lib):
+    p = cases.convection_box(3, 5).build_single_level()      # 32768 cells: 27 * 3 * 8 B * cells = 21 MB of cell slots fits, r6 would not
+    s = capi.Solver(hip_lib, p, single_level=True)
+    try:
+        n = s.size(capi.OP_A)
+        src, dst = DeviceArray(n).fill_bytes(0), DeviceArray(n).fill_bytes(0)
+        rc = hip_lib.vmult_device_noalloc(s.ctx, capi.OP_A, capi.ACTIVE, dst.ptr, src.ptr)
+        assert rc == 0, hip_lib.last_error()
+    finally:
+        s.close()
+    p = cases.convection_box(3, 6).build_single_level()      # 262144 cells: 170 MB of cell slots > 64 MiB
+    s = capi.Solver(hip_lib, p, single_level=True)
+    try:
+        n = s.size(capi.OP_A)
+        src, dst = DeviceArray(n).fill_bytes(0), DeviceArray(n).fill_bytes(0)
+        rc = hip_lib.vmult_device_noalloc(s.ctx, capi.OP_A, capi.ACTIVE, dst.ptr, src.ptr)
+        assert rc == -3
+        msg = hip_lib.last_error().decode()
+        assert "static scratch" in msg and str(64 << 20) in msg
+    finally:
+        s.close()
