@@ -95,7 +95,7 @@ SYMBOLS = [
     "set_free_surface_faces",
     "compute_diagonals", "vmult", "vmult_device", "vmult_device_noalloc", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
-    "solve", "bench_vmult", "get_cell_data_memory_consumption",
+    "solve", "bench_vmult", "get_level_kernel_path", "get_cell_data_memory_consumption",
     "get_mg_transfer_memory_consumption", "get_constraint_memory_consumption",
     "get_dof_handler_memory_consumption",
 ]
@@ -157,6 +157,7 @@ class Library:
         self.precondition = fn("precondition", C.c_int, [vp, C.c_int, c_dp, c_dp])
         self.solve = fn("solve", C.c_int, [vp, c_dp, c_dp, C.c_int, C.POINTER(SolveReport)])
         self.bench_vmult = fn("bench_vmult", C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp])
+        self.get_level_kernel_path = fn("get_level_kernel_path", C.c_int, [vp, C.c_int, c_i32p, c_i32p, c_i32p])
         for g in ("cell_data", "mg_transfer", "constraint", "dof_handler"):
             setattr(self, f"get_{g}_memory_consumption",
                     fn(f"get_{g}_memory_consumption", C.c_size_t, [vp]))
@@ -402,6 +403,12 @@ class Solver:
         t = C.c_double()
         self._check(self.lib.bench_vmult(self.ctx, which, level, n_repeat, C.byref(t)))
         return t.value
+
+    def kernel_path(self, level=ACTIVE):
+        """(bricks, layers per brick, blocks) of the kernels that apply the velocity rows of a level."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.get_level_kernel_path(self.ctx, level, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def close(self):
         if self.ctx:

@@ -9,6 +9,9 @@
 // All vectors of the solve live in HBM; the host only sees scalars (dot products, Givens
 // rotations) and -- by default, as north_star asks -- the coarsest multigrid level.
 #include <algorithm>
+#include <array>
+#include <unordered_map>
+#include <vector>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -231,7 +234,9 @@ struct agmg_ctx {
   }
 
   // doubles of slots_u the block path of a level writes beyond the cell slots (partial sums of shared nodes)
-  size_t scratch_u_need(const DeviceLevel &lv) const { return lv.bt.built ? lv.bt.n_shared_slots * (size_t)lv.dim : 0; }
+  size_t scratch_u_need(const DeviceLevel &lv) const {
+    return std::max(lv.bt.built ? lv.bt.n_shared_slots * (size_t)lv.dim : 0, lv.bk.n_partial_slots * 3);
+  }
   bool use_blocks = true;
   bool use_ell = true;     // assembled rows for the Q1 mass operator (AGMG_NO_ELL=1: matrix-free cell kernel + pull)
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
@@ -251,6 +256,10 @@ struct agmg_ctx {
   }
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                          const std::vector<uint32_t> &send_nodes);
+  int build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv);
+  bool use_bricks = true;   // brick kernels on structured 3-D levels (AGMG_NO_BRICKS=1: block / slot path)
+  int brick_z_override = 0; // AGMG_BRICK_Z: layers per brick (1, 2, 4 or 8) instead of the size-based choice
+  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && !dist(); }
   int ensure_workspace();
   int ensure_transfers();
   int ensure_mg_vectors();
@@ -265,6 +274,15 @@ struct agmg_ctx {
     return 0;
   }
 
+  // velocity-row operators (A, Stokes, B^T) of one rank: brick kernels where the level has brick tables,
+  // else the block / slot path
+  int op_velocity(const DeviceLevel &lv, const CoeffData &cd, int which, const double *src_u, const double *src_p,
+                  const EpiArgs &eu, const EpiArgs *ep = nullptr) {
+    const bool epi_ok = eu.epi == EPI_STORE || eu.epi == EPI_RESID || eu.epi == EPI_CHEB;
+    if (bricks_on(lv) && epi_ok && !((cd.newton || cd.dilation) && which == AGMG_OP_STOKES))
+      return launch_op_bricks(stream, lv, cd, which, src_u, src_p, slots_u, slots_p, eu, ep);
+    return launch_op(stream, lv, cd, which, src_u, src_p, slots_u, slots_p, eu, use_blocks, PH_ALL, ep);
+  }
   // level operators with fused epilogue: which 0 = A block, 1 = Schur mass matrix
   int apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e);
   int stokes_apply(const double *src, const EpiArgs &eu_in, double *dst);
@@ -307,6 +325,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
   dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8); dfree(l.bt.lidT);
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
+  dfree(l.bk.gnode); dfree(l.bk.bcell); dfree(l.bk.pidx); dfree(l.bk.fx_nodes); dfree(l.bk.fx_ptr); dfree(l.bk.fx_list);
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.gid_v); dfree(l.gid_p);
   dfree(l.ell_col); dfree(l.coeff.ell_val);
@@ -424,11 +443,168 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   return 0;
 }
 
+// Brick tables (agmg_internal.h BrickTables).  The structure is recovered from the cell -> node
+// table alone: two cells are x-neighbours when the +x face centre of one is the -x face centre of the
+// other (cell-local node order is lexicographic, so this also says their local axes agree); a
+// breadth-first walk over these neighbour links gives every cell integer coordinates inside its
+// consistently oriented region (a tree of the forest, or several); the regions are cut into cubes of
+// 8 x 8 x 8 cells and the cubes into bricks of Z layers.  Every lattice position of a brick must
+// receive the same node from all cells around it, every cube must be complete and every cell must
+// land in a brick: otherwise the level keeps the block path (returns 0 with bk.built == false).
+int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv) {
+  BrickTables &bk = lv.bk;
+  const int n = lv.n_cells, nn = lv.n_nodes_v;
+  if (lv.dim != 3 || n < 512 || n % 512 != 0 || (unsigned)nn > BRICK_NODE_MASK || dist()) return 0;
+  const uint32_t *cnv = hl.cnv.data();
+  // face centres: local nodes (0,1,1) (2,1,1) (1,0,1) (1,2,1) (1,1,0) (1,1,2)
+  static const int FC[6] = {12, 14, 10, 16, 4, 22};
+  std::vector<int32_t> first(nn, -1);
+  std::vector<int32_t> nbr((size_t)n * 6, -1);
+  for (int cell = 0; cell < n; ++cell)
+    for (int f = 0; f < 6; ++f) {
+      const uint32_t node = cnv[(size_t)cell * 27 + FC[f]];
+      const int32_t me = cell * 6 + f;
+      if (first[node] < 0) { first[node] = me; continue; }
+      const int32_t other = first[node];
+      const int oc = other / 6, of = other % 6;
+      if ((of ^ 1) == f && oc != cell && nbr[(size_t)cell * 6 + f] < 0 && nbr[(size_t)oc * 6 + of] < 0) {
+        nbr[(size_t)cell * 6 + f] = oc;
+        nbr[(size_t)oc * 6 + of] = cell;
+      }
+    }
+  std::vector<int32_t>().swap(first);
+  // integer coordinates by breadth-first search; regions numbered in order of their first cell
+  std::vector<int32_t> coord((size_t)n * 3, 0), region(n, -1);
+  std::vector<int32_t> queue;
+  queue.reserve(n);
+  int n_regions = 0;
+  std::vector<std::array<int32_t, 3>> rmin;
+  for (int seed = 0; seed < n; ++seed) {
+    if (region[seed] >= 0) continue;
+    const int r = n_regions++;
+    region[seed] = r;
+    std::array<int32_t, 3> mn = {0, 0, 0};
+    size_t head = queue.size();
+    queue.push_back(seed);
+    while (head < queue.size()) {
+      const int cell = queue[head++];
+      for (int f = 0; f < 6; ++f) {
+        const int32_t o = nbr[(size_t)cell * 6 + f];
+        if (o < 0 || region[o] >= 0) continue;
+        region[o] = r;
+        for (int d = 0; d < 3; ++d) coord[(size_t)o * 3 + d] = coord[(size_t)cell * 3 + d];
+        coord[(size_t)o * 3 + f / 2] += (f & 1) ? 1 : -1;
+        for (int d = 0; d < 3; ++d) mn[d] = std::min(mn[d], coord[(size_t)o * 3 + d]);
+        queue.push_back(o);
+      }
+    }
+    rmin.push_back(mn);
+  }
+  std::vector<int32_t>().swap(queue);
+  // cubes: key (region, i >> 3, j >> 3, k >> 3), numbered in order of their first cell
+  std::unordered_map<uint64_t, int32_t> cube_of;
+  std::vector<int32_t> cube_cells;   // [cube][512], index (k & 7) * 64 + (j & 7) * 8 + (i & 7)
+  for (int cell = 0; cell < n; ++cell) {
+    int32_t q[3];
+    for (int d = 0; d < 3; ++d) {
+      q[d] = coord[(size_t)cell * 3 + d] - rmin[region[cell]][d];
+      coord[(size_t)cell * 3 + d] = q[d];
+    }
+    if ((q[0] >> 3) >= (1 << 14) || (q[1] >> 3) >= (1 << 14) || (q[2] >> 3) >= (1 << 14) || region[cell] >= (1 << 20)) return 0;
+    const uint64_t key = ((uint64_t)region[cell] << 42) | ((uint64_t)(q[2] >> 3) << 28) | ((uint64_t)(q[1] >> 3) << 14) | (uint64_t)(q[0] >> 3);
+    auto it = cube_of.find(key);
+    int32_t cube;
+    if (it == cube_of.end()) {
+      cube = (int32_t)(cube_cells.size() / 512);
+      cube_of.emplace(key, cube);
+      cube_cells.resize(cube_cells.size() + 512, -1);
+    } else cube = it->second;
+    int32_t &slot = cube_cells[(size_t)cube * 512 + (q[2] & 7) * 64 + (q[1] & 7) * 8 + (q[0] & 7)];
+    if (slot >= 0) return 0;   // two cells at one position: not a lattice
+    slot = cell;
+  }
+  const int n_cubes = (int)(cube_cells.size() / 512);
+  if ((size_t)n_cubes * 512 != (size_t)n) return 0;   // some cube is incomplete
+  // layers per brick: enough bricks to fill the chip on small levels, whole cubes on large ones
+  int Z = 8;
+  if (n_cubes < 512) { Z = 1; while (Z < 8 && n_cubes * 8 / (2 * Z) >= 512) Z *= 2; }
+  if (brick_z_override == 1 || brick_z_override == 2 || brick_z_override == 4 || brick_z_override == 8) Z = brick_z_override;
+  const int per_cube = 8 / Z, nb = n_cubes * per_cube;
+  const int nplanes = 2 * Z + 1, latn = BRICK_PLANE * nplanes;
+  if ((uint64_t)nb * latn > 0xFFFFFFFFull) return 0;
+  // surface enumeration of the lattice
+  std::vector<uint16_t> pidx(latn, 0xFFFF);
+  int npb = 0;
+  for (int K = 0; K < nplanes; ++K)
+    for (int J = 0; J < BRICK_LAT; ++J)
+      for (int I = 0; I < BRICK_LAT; ++I)
+        if (K == 0 || K == nplanes - 1 || J == 0 || J == BRICK_LAT - 1 || I == 0 || I == BRICK_LAT - 1)
+          pidx[(size_t)K * BRICK_PLANE + J * BRICK_LAT + I] = (uint16_t)npb++;
+  if ((uint64_t)nb * npb > 0xFFFFFFFFull) return 0;
+  std::vector<uint32_t> gnode((size_t)nb * latn, 0xFFFFFFFFu), bcell((size_t)nb * Z * 64);
+  for (int cube = 0; cube < n_cubes; ++cube)
+    for (int sub = 0; sub < per_cube; ++sub) {
+      const int brick = cube * per_cube + sub;
+      uint32_t *lat = &gnode[(size_t)brick * latn];
+      for (int kl = 0; kl < Z; ++kl)
+        for (int jj = 0; jj < 8; ++jj)
+          for (int ii = 0; ii < 8; ++ii) {
+            const int cell = cube_cells[(size_t)cube * 512 + (sub * Z + kl) * 64 + jj * 8 + ii];
+            bcell[((size_t)brick * Z + kl) * 64 + jj * 8 + ii] = (uint32_t)cell;
+            for (int a = 0; a < 27; ++a) {
+              const int ax = a % 3, ay = (a / 3) % 3, az = a / 9;
+              uint32_t &e = lat[(size_t)(2 * kl + az) * BRICK_PLANE + (2 * jj + ay) * BRICK_LAT + 2 * ii + ax];
+              const uint32_t node = cnv[(size_t)cell * 27 + a];
+              if (e == 0xFFFFFFFFu) e = node;
+              else if (e != node) return 0;   // neighbouring cells disagree: not a structured brick
+            }
+          }
+    }
+  // ownership: the first brick (and lattice position) that lists a node owns it
+  std::vector<uint32_t> owner(nn, 0xFFFFFFFFu), fx_count(nn, 0);
+  std::vector<std::pair<uint32_t, uint32_t>> pairs;   // (node, partial slot)
+  for (int brick = 0; brick < nb; ++brick)
+    for (int l = 0; l < latn; ++l) {
+      uint32_t &e = gnode[(size_t)brick * latn + l];
+      const uint32_t node = e;
+      if (owner[node] == 0xFFFFFFFFu) {
+        owner[node] = (uint32_t)((size_t)brick * latn + l);
+        e = node | ((uint32_t)cmv[node] << 29);
+      } else {
+        if ((owner[node] / (uint32_t)latn) == (uint32_t)brick || pidx[l] == 0xFFFF) return 0;   // a node twice in one brick / shared from inside
+        e = node | BRICK_PARTIAL | ((uint32_t)cmv[node] << 29);
+        pairs.emplace_back(node, (uint32_t)((size_t)brick * npb + pidx[l]));
+        ++fx_count[node];
+      }
+    }
+  for (int node = 0; node < nn; ++node)
+    if (owner[node] == 0xFFFFFFFFu) return 0;   // a node no cell touches
+  std::vector<uint32_t>().swap(owner);
+  std::vector<uint32_t> fx_nodes, fx_ptr(1, 0), fx_index(nn, 0), fx_list(pairs.size());
+  for (int node = 0; node < nn; ++node)
+    if (fx_count[node]) {
+      fx_index[node] = (uint32_t)fx_nodes.size();
+      fx_nodes.push_back((uint32_t)node | ((uint32_t)cmv[node] << 29));
+      fx_ptr.push_back(fx_ptr.back() + fx_count[node]);
+    }
+  std::vector<uint32_t> fill(fx_ptr.begin(), fx_ptr.end() - 1);
+  for (auto &pr : pairs) fx_list[fill[fx_index[pr.first]]++] = pr.second;   // pairs are in brick order
+  bk.Z = Z; bk.n_bricks = nb; bk.latn = latn; bk.npb = npb;
+  bk.n_fix = (int)fx_nodes.size();
+  bk.n_partial_slots = (size_t)nb * npb;
+  CHECK(upload(&bk.gnode, gnode)); CHECK(upload(&bk.bcell, bcell)); CHECK(upload(&bk.pidx, pidx));
+  CHECK(upload(&bk.fx_nodes, fx_nodes)); CHECK(upload(&bk.fx_ptr, fx_ptr)); CHECK(upload(&bk.fx_list, fx_list));
+  bk.bytes = (gnode.size() + bcell.size() + fx_nodes.size() + fx_ptr.size() + fx_list.size()) * 4 + pidx.size() * 2;
+  bk.built = true;
+  return 0;
+}
+
 int agmg_ctx::ensure_workspace() {
   size_t nu = 0, np = 0;
   const int dim = opt.dim, NV = ipow(3, dim), NP = ipow(2, dim);
   for (auto &l : L) {
     nu = std::max(nu, (size_t)NV * l.cstride * dim);
+    nu = std::max(nu, l.bk.n_partial_slots * 3);
     np = std::max(np, (size_t)NP * l.cstride * dim);
   }
   if (nu > slots_u_cap) { dfree(slots_u); CHECK(dalloc(&slots_u, nu)); slots_u_cap = nu; }
@@ -655,7 +831,7 @@ int agmg_ctx::ensure_transfers() {
 int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e) {
   const DeviceLevel &lv = L[l];
   if (!dist()) {
-    if (which == 0) return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks);
+    if (which == 0) return op_velocity(lv, cd, AGMG_OP_A, x, nullptr, e);
     if (mass_ell(lv, cd)) return launch_mass_ell(stream, lv, cd, x, e);
     CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
     return launch_pull_p(stream, lv, slots_p, 1, e);
@@ -679,7 +855,7 @@ int agmg_ctx::bt_residual(double *dst, const double *b, const double *p) {
   const DeviceLevel &lv = fin();
   EpiArgs e;
   e.epi = b ? EPI_RESID : EPI_STORE; e.dst = dst; e.b = b; e.x = nullptr;
-  if (!dist()) return launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks);
+  if (!dist()) return op_velocity(lv, active_coeff(), AGMG_OP_BT, nullptr, p, e);
   CHECK(update_ghosts(lv.xp, p));
   CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_GHOST));
   CHECK(compress(lv.xv));
@@ -714,7 +890,7 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
   ep.dst = dst + nu; ep.x = src + nu;
   if (eu_in.b) ep.b = eu_in.b + nu;
   if (!dist()) {
-    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_ALL, &ep));
+    CHECK(op_velocity(lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, eu, &ep));
     // boundary-face loop of StokesOperator::apply_add (matrix_free_operators.cc:343-353)
     return launch_face_term(stream, lv.dim, faces, lv.cmask_v, src, dst, eu_in.epi == EPI_RESID ? -1.0 : 1.0);
   }
@@ -1681,6 +1857,8 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   auto *c = new agmg_ctx();
   c->opt = *opt;
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_NO_BRICKS")) c->use_bricks = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_BRICK_Z")) c->brick_z_override = atoi(e);
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_BATCHED_SETUP")) c->use_batched_setup = atoi(e) == 0;
@@ -1926,6 +2104,10 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   }
   CHECK(c->build_block_tables(lv, hl, cmv, c->send_nodes_h[0][level]));
   lv.bytes_tables += lv.bt.bytes;
+  if (c->use_bricks) {
+    CHECK(c->build_brick_tables(lv, hl, cmv));
+    lv.bytes_tables += lv.bk.bytes;
+  }
   CHECK(c->dalloc(&lv.inv_diag_A, (size_t)lv.n_dofs_v()));
   CHECK(c->dalloc(&lv.inv_diag_M, (size_t)lv.n_dofs_p()));
   lv.set = true;
@@ -2200,14 +2382,14 @@ static int vmult_device_impl(agmg_ctx *c, int which, int level, double *dst, con
       if (level == AGMG_ACTIVE) return c->stokes_vmult(dst, src);   // with the active operator's face terms
       EpiArgs ep = e;
       ep.dst = dst + nu; ep.x = src + nu;
-      return launch_op(c->stream, lv, cd, AGMG_OP_STOKES, src, src + nu, c->slots_u, c->slots_p, e, c->use_blocks, PH_ALL, &ep);
+      return c->op_velocity(lv, cd, AGMG_OP_STOKES, src, src + nu, e, &ep);
     }
     default: {  // B^T: both blocks of dst are written (vmult zeroes dst first)
       if (c->dist()) {
         if (l != c->nl() - 1 || &cd != &c->active_coeff()) { set_error("distributed B^T vmult: active mesh only"); return -2; }
         CHECK(c->bt_residual(dst, nullptr, src + nu));
       } else {
-        CHECK(launch_op(c->stream, lv, cd, AGMG_OP_BT, nullptr, src + nu, c->slots_u, nullptr, e, c->use_blocks));
+        CHECK(c->op_velocity(lv, cd, AGMG_OP_BT, nullptr, src + nu, e));
       }
       return vec_set(c->stream, dst + nu, 0.0, np);
     }
@@ -2473,6 +2655,16 @@ int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *se
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   c->dfree(src); c->dfree(dst);
   return rc;
+}
+
+int agmg_get_level_kernel_path(const agmg_ctx *c, int level, int32_t *n_bricks, int32_t *layers_per_brick, int32_t *n_blocks) {
+  if (!c || (level != AGMG_ACTIVE && (level < 0 || level >= (int)c->L.size()))) { set_error("bad level"); return -1; }
+  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->L.back() : c->L[level];
+  const bool bricks = c->bricks_on(lv);
+  if (n_bricks) *n_bricks = bricks ? lv.bk.n_bricks : 0;
+  if (layers_per_brick) *layers_per_brick = bricks ? lv.bk.Z : 0;
+  if (n_blocks) *n_blocks = (c->use_blocks && lv.bt.built) ? lv.bt.n_blocks : 0;
+  return 0;
 }
 
 size_t agmg_get_cell_data_memory_consumption(const agmg_ctx *c) {

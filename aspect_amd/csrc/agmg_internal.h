@@ -92,6 +92,29 @@ struct BlockTables {
   size_t bytes = 0;
 };
 
+// Brick decomposition of a structured 3-D level ("bricks"): the cells of the level are
+// tiled by bricks of 8 x 8 x Z cells (Z layers of 64 cells); one workgroup marches a brick layer by
+// layer (kernels_brick.hip).  A brick's (17 x 17 x (2Z+1)) lattice of velocity nodes is listed in
+// `gnode`; a node that several bricks touch is owned by the first of them (brick order): the owner
+// stores the row to dst (epilogue fused, with its own share of the sum), every other brick writes
+// its share to a partial-sum slot, and a fix-up pass adds those shares to the owner's row.
+constexpr uint32_t BRICK_NODE_MASK = 0x0FFFFFFFu;   // low 28 bits: node
+constexpr uint32_t BRICK_PARTIAL = 0x10000000u;     // bit 28: this brick does not own the node
+constexpr int BRICK_NX = 8, BRICK_LAT = 17, BRICK_PLANE = 17 * 17;
+struct BrickTables {
+  bool built = false;
+  int Z = 0, n_bricks = 0, latn = 0, npb = 0;   // layers per brick, bricks, lattice nodes and surface slots per brick
+  uint32_t *gnode = nullptr;    // [n_bricks][latn]: node | BRICK_PARTIAL | cmask << 29
+  uint32_t *bcell = nullptr;    // [n_bricks][Z][64]: cell of (layer, lane = i + 8 j)
+  uint16_t *pidx = nullptr;     // [latn]: surface enumeration of the lattice (0xFFFF inside)
+  int n_fix = 0;                // owned nodes that receive partial sums
+  uint32_t *fx_nodes = nullptr; // [n_fix] node | cmask << 29
+  uint32_t *fx_ptr = nullptr;   // [n_fix + 1]
+  uint32_t *fx_list = nullptr;  // partial slots (brick * npb + surface index), brick order
+  size_t n_partial_slots = 0;   // n_bricks * npb (doubles needed: * 3)
+  size_t bytes = 0;
+};
+
 // Ghost exchange of one node space (Q2 velocity nodes or Q1 pressure nodes) of one level
 // (deal.II update_ghost_values / compress(add) of LinearAlgebra::distributed::Vector).
 // Ghost nodes sit behind the owned ones, grouped by owner rank; `send_nodes` lists per neighbour
@@ -129,6 +152,7 @@ struct DeviceLevel {
   uint32_t *pull_ptr_p = nullptr;
   uint32_t *pull_list_p = nullptr; // [n_cells * 2^dim]
   BlockTables bt;
+  BrickTables bk;
   CoeffData coeff;
   double *inv_diag_A = nullptr, *inv_diag_M = nullptr;
   // transfer, stored on the FINE level: per fine node the parent cell (on
@@ -207,6 +231,10 @@ int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *
 int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *recv,
                              double *dst_u, double sign);
 
+// brick path (kernels_brick.hip): whole operator application on a level with BrickTables; partial sums go
+// to `partials` (3 * n_partial_slots doubles).  ep (Stokes): also finish the pressure rows.
+int launch_op_bricks(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
+                     const double *src_p, double *partials, double *slots_p, const EpiArgs &eu, const EpiArgs *ep);
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,
               int phase = PH_ALL, const EpiArgs *ep = nullptr);

@@ -172,7 +172,8 @@ struct BrickXch {
 template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN, bool NEWTON = false, class EX = WaveXch<DIM>>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, EX &ex, double *G,
-                                             double *pout, const double *eta_tile, double *u) {
+                                             double *pout, const double *eta_tile, double *u,
+                                             const int eta_stride = KDims<DIM>::CPW) {
   constexpr int NV = KDims<DIM>::NV;
   constexpr int NP = KDims<DIM>::NP;
   constexpr int NPLP = NP / 2;  // pressure nodes per plane
@@ -420,7 +421,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       const double wq = (DIM == 3) ? wq1(x) * wq1(qy) * wq1(qz) : wq1(x) * wq1(qy);
       double etav = 1.0;
 #if !(AGMG_ABLATE & 8)
-      if (PERQ) etav = ETA_LDS ? eta_tile[(base + x) * KDims<DIM>::CPW + j] : A.etaT[(size_t)(base + x) * cs + cell];
+      if (PERQ) etav = ETA_LDS ? eta_tile[(base + x) * eta_stride + j] : A.etaT[(size_t)(base + x) * cs + cell];
 #endif
       const double f = wq * etav;
       if (HAS_U) {
@@ -593,6 +594,110 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
     for (int l = 0; l < 9; ++l) interp3T(G[l], G[l + 9], G[l + 18]);
   }
+}
+
+
+// ---- node-owner pull + vector epilogue -----------------------------------------------------
+struct PullArgs {
+  const uint32_t *ptr, *list;
+  const double *slots;
+  const uint8_t *cmask;
+  int node0, n_range;       // nodes [node0, node0 + n_range)
+  uint32_t recv_base;       // list entries >= recv_base address recv[(entry - recv_base) * NC + c]
+  const double *recv;       // remote partial sums (ghost exchange), or nullptr
+  double *ghost_out;        // != nullptr: raw sums to ghost_out[(node - node0) * NC + c], no epilogue
+  EpiArgs e;
+};
+
+// vector epilogue shared by the pull, block and fix-up kernels; false = leave dst untouched
+__device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, const double sum, const bool con,
+                                          double &out) {
+  switch (e.epi) {
+    case EPI_STORE:
+      out = con ? (e.x ? e.x[t] : 0.0) : sum;
+      return true;
+    case EPI_RESID:
+      out = e.b[t] - (con ? (e.x ? e.x[t] : 0.0) : sum);
+      return true;
+    case EPI_CHEB: {
+      const double x = e.x[t];
+      const double Ax = con ? x : sum;
+      double v = fma(e.f2 * e.dinv[t], e.b[t] - Ax, (1.0 + e.f1) * x);
+      if (e.xold) v = fma(-e.f1, e.xold[t], v);
+      out = v;
+      return true;
+    }
+    case EPI_ADD:
+      if (con) return false;
+      out = e.dst[t] + sum;
+      return true;
+    case EPI_DIAG:
+      out = 1.0 / (con ? 1.0 : sum);
+      return true;
+    default:
+      out = con ? 1.0 : sum;
+      return true;
+  }
+}
+
+// NC: components per node (one thread each); NPARTS: partial values per slot summed by the thread
+template <int NC, int NPARTS>
+__device__ __forceinline__ void pull_body(const PullArgs &P, const unsigned block) {
+  const long tl = (long)block * 256 + threadIdx.x;
+  if (tl >= (long)P.n_range * NC) return;
+  const int nl = (int)(tl / NC), c = (int)(tl - (long)nl * NC);
+  const int node = P.node0 + nl;
+  const uint32_t s = P.ptr[node], en = P.ptr[node + 1];
+  double sum = 0.0;
+  for (uint32_t k = s; k < en; ++k) {
+    const uint32_t ent = P.list[k];
+    if (ent >= P.recv_base) {
+      sum += P.recv[(size_t)(ent - P.recv_base) * NC + c];
+    } else {
+      const size_t base = (size_t)ent * (NC * NPARTS) + c * NPARTS;
+#pragma unroll
+      for (int part = 0; part < NPARTS; ++part) sum += P.slots[base + part];
+    }
+  }
+  if (P.ghost_out) { P.ghost_out[tl] = sum; return; }
+  const size_t t = (size_t)node * NC + c;
+  const bool con = P.cmask ? ((P.cmask[node] >> c) & 1u) : false;
+  double out;
+  if (epi_value(P.e, t, sum, con, out)) P.e.dst[t] = out;
+}
+
+// block index -> work item such that the 8 groups of workgroups {blockIdx % 8 = x} (one XCD, one L2
+// each) take contiguous runs of items; a bijection on [0, nb)
+__device__ __forceinline__ unsigned xcd_contiguous(const unsigned b, const unsigned nb) {
+  const unsigned q = nb >> 3, rem = nb & 7u, x = b & 7u, i = b >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
+}
+
+inline CellArgs make_cell_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
+                   double *slp) {
+  CellArgs a;
+  a.n_cells = L.n_cells;
+  a.cstride = L.cstride;
+  a.cnvT = L.cnvT;
+  a.cnpT = L.cnpT;
+  a.hT = L.cell_hT;
+  a.invJT = L.invJT;
+  a.jxwT = L.jxwT;
+  a.etaT = cd.etaT;
+  a.lambda = cd.lambda;
+  a.src_u = su;
+  a.src_p = sp;
+  a.slots_u = slu;
+  a.slots_p = slp;
+  a.nw_strain = cd.nw_strain;
+  a.nw_dEde = cd.nw_dEde;
+  a.nw_dEdp = cd.nw_dEdp;
+  a.nw_symmetrize = cd.nw_symmetrize;
+  a.nw_on = cd.newton ? 1 : 0;
+  a.dil_lhs = cd.dilation ? cd.dil_lhs : nullptr;
+  a.dil_de = cd.dil_de;
+  a.dil_dp = cd.dil_dp;
+  return a;
 }
 
 

@@ -169,8 +169,6 @@ __global__ void __launch_bounds__(256) k_mass_ell_assemble(const CellArgs A, con
   for (int kk = 0; kk < W; ++kk) M.val[kk * st + n] = val[kk];
 }
 
-__device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, const double sum, const bool con,
-                                          double &out);
 struct EllMulArgs {
   const uint32_t *col;
   const double *val;
@@ -434,74 +432,6 @@ __global__ void __launch_bounds__(256) k_diag_p(const CellArgs A, int nqv, int g
   A.slots_p[(size_t)b * cs + cell] = acc;
 }
 
-// ---- node-owner pull + vector epilogue -----------------------------------------------------
-struct PullArgs {
-  const uint32_t *ptr, *list;
-  const double *slots;
-  const uint8_t *cmask;
-  int node0, n_range;       // nodes [node0, node0 + n_range)
-  uint32_t recv_base;       // list entries >= recv_base address recv[(entry - recv_base) * NC + c]
-  const double *recv;       // remote partial sums (ghost exchange), or nullptr
-  double *ghost_out;        // != nullptr: raw sums to ghost_out[(node - node0) * NC + c], no epilogue
-  EpiArgs e;
-};
-
-// vector epilogue shared by the pull, block and fix-up kernels; false = leave dst untouched
-__device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, const double sum, const bool con,
-                                          double &out) {
-  switch (e.epi) {
-    case EPI_STORE:
-      out = con ? (e.x ? e.x[t] : 0.0) : sum;
-      return true;
-    case EPI_RESID:
-      out = e.b[t] - (con ? (e.x ? e.x[t] : 0.0) : sum);
-      return true;
-    case EPI_CHEB: {
-      const double x = e.x[t];
-      const double Ax = con ? x : sum;
-      double v = fma(e.f2 * e.dinv[t], e.b[t] - Ax, (1.0 + e.f1) * x);
-      if (e.xold) v = fma(-e.f1, e.xold[t], v);
-      out = v;
-      return true;
-    }
-    case EPI_ADD:
-      if (con) return false;
-      out = e.dst[t] + sum;
-      return true;
-    case EPI_DIAG:
-      out = 1.0 / (con ? 1.0 : sum);
-      return true;
-    default:
-      out = con ? 1.0 : sum;
-      return true;
-  }
-}
-
-// NC: components per node (one thread each); NPARTS: partial values per slot summed by the thread
-template <int NC, int NPARTS>
-__device__ __forceinline__ void pull_body(const PullArgs &P, const unsigned block) {
-  const long tl = (long)block * 256 + threadIdx.x;
-  if (tl >= (long)P.n_range * NC) return;
-  const int nl = (int)(tl / NC), c = (int)(tl - (long)nl * NC);
-  const int node = P.node0 + nl;
-  const uint32_t s = P.ptr[node], en = P.ptr[node + 1];
-  double sum = 0.0;
-  for (uint32_t k = s; k < en; ++k) {
-    const uint32_t ent = P.list[k];
-    if (ent >= P.recv_base) {
-      sum += P.recv[(size_t)(ent - P.recv_base) * NC + c];
-    } else {
-      const size_t base = (size_t)ent * (NC * NPARTS) + c * NPARTS;
-#pragma unroll
-      for (int part = 0; part < NPARTS; ++part) sum += P.slots[base + part];
-    }
-  }
-  if (P.ghost_out) { P.ghost_out[tl] = sum; return; }
-  const size_t t = (size_t)node * NC + c;
-  const bool con = P.cmask ? ((P.cmask[node] >> c) & 1u) : false;
-  double out;
-  if (epi_value(P.e, t, sum, con, out)) P.e.dst[t] = out;
-}
 template <int NC, int NPARTS>
 __global__ void __launch_bounds__(256) k_pull(const PullArgs P) { pull_body<NC, NPARTS>(P, blockIdx.x); }
 
@@ -522,12 +452,6 @@ __global__ void __launch_bounds__(256) k_pull(const PullArgs P) { pull_body<NC, 
 #else
 #define AGMG_STAMP(k)
 #endif
-// block index -> work item such that the 8 groups of workgroups {blockIdx % 8 = x} (one XCD, one L2
-// each) take contiguous runs of items; a bijection on [0, nb)
-__device__ __forceinline__ unsigned xcd_contiguous(const unsigned b, const unsigned nb) {
-  const unsigned q = nb >> 3, rem = nb & 7u, x = b & 7u, i = b >> 3;
-  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
-}
 struct BlkArgs {
   unsigned long long *dbg;
   const uint4 *blk_hdr;      // per block {unique nodes, exclusive nodes, first shared slot, 0}
@@ -896,33 +820,6 @@ __global__ void __launch_bounds__(128) k_face_add_received(const FaceTerm F, con
     if (!((m >> c) & 1)) dst[(size_t)node * DIM + c] += sign * sum[c];
 }
 
-CellArgs make_args(const DeviceLevel &L, const CoeffData &cd, const double *su, const double *sp, double *slu,
-                   double *slp) {
-  CellArgs a;
-  a.n_cells = L.n_cells;
-  a.cstride = L.cstride;
-  a.cnvT = L.cnvT;
-  a.cnpT = L.cnpT;
-  a.hT = L.cell_hT;
-  a.invJT = L.invJT;
-  a.jxwT = L.jxwT;
-  a.etaT = cd.etaT;
-  a.lambda = cd.lambda;
-  a.src_u = su;
-  a.src_p = sp;
-  a.slots_u = slu;
-  a.slots_p = slp;
-  a.nw_strain = cd.nw_strain;
-  a.nw_dEde = cd.nw_dEde;
-  a.nw_dEdp = cd.nw_dEdp;
-  a.nw_symmetrize = cd.nw_symmetrize;
-  a.nw_on = cd.newton ? 1 : 0;
-  a.dil_lhs = cd.dilation ? cd.dil_lhs : nullptr;
-  a.dil_de = cd.dil_de;
-  a.dil_dp = cd.dil_dp;
-  return a;
-}
-
 template <int DIM, int OP, bool GEN>
 void launch_cells_t(hipStream_t s, const CellArgs &a, bool comp, bool perq) {
   const int cpb = (64 / DIM) * WAVES_PER_BLOCK;
@@ -1012,7 +909,7 @@ int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, in
                     const double *src_p, double *slots_u, double *slots_p) {
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
-  const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
+  const CellArgs a = make_cell_args(L, cd, src_u, src_p, slots_u, slots_p);
   const bool perq = cd.nqv > 1;
   // the compressible term only exists where the velocity is read (A, Stokes)
   const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;
@@ -1031,7 +928,7 @@ int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, in
 int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, double *slots_p) {
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
-  const CellArgs a = make_args(L, cd, nullptr, src_p, nullptr, slots_p);
+  const CellArgs a = make_cell_args(L, cd, nullptr, src_p, nullptr, slots_p);
   const dim3 grid((L.n_cells + 255) / 256), block(256);
   const bool perq = cd.nqv > 1;
   const bool gen = L.geom == AGMG_GEOM_GENERAL;
@@ -1051,7 +948,7 @@ int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffDat
   if (!cd.set || !L.ell_col || !cd.ell_val) { set_error("mass rows: tables missing"); return -4; }
   if (L.ell_stride > L.n_nodes_p)   // padding rows
     AGMG_HIP_CHECK(hipMemsetAsync(cd.ell_val, 0, (size_t)L.ell_w * L.ell_stride * sizeof(double), s));
-  const CellArgs a = make_args(L, cd, nullptr, nullptr, nullptr, nullptr);
+  const CellArgs a = make_cell_args(L, cd, nullptr, nullptr, nullptr, nullptr);
   const EllArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.pull_ptr_p, L.pull_list_p};
   const dim3 grid((L.n_nodes_p + 255) / 256), block(256);
   const bool perq = cd.nqv > 1;
@@ -1084,7 +981,7 @@ int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &c
                          bool use_ell) {
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (!L.mass_fusable || prog.n < 1 || prog.n > SM_MAX_STEPS) { set_error("fused mass smoother: level or program does not fit"); return -1; }
-  const CellArgs a = make_args(L, cd, nullptr, nullptr, nullptr, nullptr);
+  const CellArgs a = make_cell_args(L, cd, nullptr, nullptr, nullptr, nullptr);
   const MassSmArgs m{L.pull_ptr_p, L.pull_list_p, L.cmask_p, dinv, b, x_in, x_out, resid_out, L.n_nodes_p};
   const dim3 grid(1), block(MS_THREADS);
   if (use_ell) {
@@ -1111,7 +1008,7 @@ int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &c
 int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u, double *slots_p) {
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
-  const CellArgs a = make_args(L, cd, nullptr, nullptr, slots_u, slots_p);
+  const CellArgs a = make_cell_args(L, cd, nullptr, nullptr, slots_u, slots_p);
   const int nv = L.dim == 3 ? 27 : 9, np = L.dim == 3 ? 8 : 4;
   const int gen = L.geom == AGMG_GEOM_GENERAL;
   const dim3 block(256);
@@ -1199,7 +1096,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
     return 0;
   };
   if (phase == PH_OWNED) return fix(0, bt.n_shared_owned, false);
-  const CellArgs a = make_args(L, cd, src_u, src_p, slots_u, slots_p);
+  const CellArgs a = make_cell_args(L, cd, src_u, src_p, slots_u, slots_p);
   static unsigned long long *dbg_buf = nullptr;
 #if AGMG_ABLATE & 1024
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)4000000 * 8 * 8);

@@ -317,6 +317,12 @@ int agmg_solve(agmg_ctx *ctx, const double *rhs, double *x, int solve_newton_sys
  *   (the in-solver harness local_smoothing.cc:1234-1375). */
 int agmg_bench_vmult(agmg_ctx *ctx, int which, int level, int n_repeat, double *seconds_per_vmult);
 
+/* Which kernels apply the velocity-row operators of a level (diagnostics and benchmark reports; the
+ * reference's counterpart is the "Output details" block of local_smoothing.cc:1007-1017): bricks of
+ * 8 x 8 x layers cells (structured 3-D levels), else blocks of consecutive cells, else (both 0) the
+ * slot path. */
+int agmg_get_level_kernel_path(const agmg_ctx *ctx, int level, int32_t *n_bricks, int32_t *layers_per_brick, int32_t *n_blocks);
+
 /* memory getters (stokes_matrix_free.h:75-98; postprocess/memory_statistics.cc:44-59) */
 size_t agmg_get_cell_data_memory_consumption(const agmg_ctx *ctx);
 size_t agmg_get_mg_transfer_memory_consumption(const agmg_ctx *ctx);

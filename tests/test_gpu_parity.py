@@ -513,3 +513,72 @@ def test_option_validation(hip_lib):
         setattr(opt, field, value)
         assert not hip_lib.create(C.byref(opt))
         assert word in hip_lib.last_error()
+
+
+BRICK_CASES = {
+    "nsinker_r3_harmonic": lambda: cases.nsinker_box(3, n_sinkers=4, ratio=1e4),
+    "box3d_r3_freeslip_perq": lambda: cases.convection_box(3, 3),
+    "deformed3d_r3_perq": lambda: cases.deformed_sinker_box(3, 3),
+    "nsinker_r3_two_trees": lambda: _with_reps(cases.nsinker_box(3, n_sinkers=4, ratio=1e4), [2, 1, 1]),
+    "box3d_r3_cellwise_numbering": lambda: _with_numbering(cases.convection_box(3, 3), "cellwise"),
+}
+
+
+def _with_reps(p, reps):
+    p.reps = reps
+    return p
+
+
+def _with_numbering(p, numbering):
+    p.numbering = numbering
+    return p
+
+
+@pytest.mark.parametrize("layers", [1, 2, 4, 8])
+@pytest.mark.parametrize("case", sorted(BRICK_CASES))
+def test_brick_kernels_layers_per_brick(case, layers, hip_lib, oracle_lib, monkeypatch):
+    """The brick kernels (kernels_brick.hip) with every number of layers per brick (the library picks it by
+    level size; AGMG_BRICK_Z forces it): operators on the finest level against the oracle, the compressible
+    variants, and a V-cycle + block preconditioner (Chebyshev and residual epilogues on every level that has
+    bricks)."""
+    monkeypatch.setenv("AGMG_BRICK_Z", str(layers))
+    p = BRICK_CASES[case]().build()
+    g, o = capi.Solver(hip_lib, p), capi.Solver(oracle_lib, p)
+    fin = p.hier.finest
+    try:
+        assert g.kernel_path() == (fin.n_cells // (64 * layers), layers, g.kernel_path()[2])
+        assert g.kernel_path(p.hier.n_levels - 2)[0] == 0      # 64 cells per tree: no cube of 8^3
+        for level in (capi.ACTIVE, p.hier.n_levels - 1):
+            for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT):
+                src = rand_vec(g.size(which, level), 31 + which, fin, zero_constrained=False)
+                assert relerr(g.vmult(which, src, level), o.vmult(which, src, level)) < RTOL, (which, level)
+        for s in (g, o):
+            s.setup_smoothers()
+        src = rand_vec(g.size(capi.OP_A), 17, fin)
+        assert relerr(g.vcycle(capi.OP_A, src), o.vcycle(capi.OP_A, src)) < 1e-9
+        src = rand_vec(g.size(capi.OP_STOKES), 18, fin)
+        assert relerr(g.precondition(src), o.precondition(src)) < 1e-9
+        for s in (g, o):
+            for l in range(p.hier.n_levels):
+                s._set_coeff(l, p.eta_levels[l], is_compressible=1)
+            s._set_coeff(capi.ACTIVE, p.eta_active, is_compressible=1)
+        for which in (capi.OP_A, capi.OP_STOKES):
+            src = rand_vec(g.size(which), 41 + which, fin)
+            assert relerr(g.vmult(which, src), o.vmult(which, src)) < RTOL, ("compressible", which)
+    finally:
+        g.close(); o.close()
+
+
+def test_brick_kernels_equal_block_kernels(hip_lib, monkeypatch):
+    """Same operator through the brick path and through the block path (AGMG_NO_BRICKS=1)."""
+    p = cases.nsinker_box(4, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE)
+    p.build_single_level()
+    src = rand_vec(p.hier.finest.n_dofs_v + p.hier.finest.n_dofs_p, 3, p.hier.finest)
+    out = []
+    for no_bricks in ("0", "1"):
+        monkeypatch.setenv("AGMG_NO_BRICKS", no_bricks)
+        g = capi.Solver(hip_lib, p, single_level=True)
+        assert (g.kernel_path()[0] > 0) == (no_bricks == "0")
+        out.append(g.vmult(capi.OP_STOKES, src))
+        g.close()
+    assert relerr(out[0], out[1]) < 1e-13

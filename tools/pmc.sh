@@ -18,7 +18,7 @@ for f in glob.glob(out + "/p*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
-    if "k_cells" in k or "k_fix" in k or "k_pull" in k:
+    if "k_cells" in k or "k_fix" in k or "k_pull" in k or "k_brick" in k:
         print(k)
         for c, v in sorted(d.items()):
             print(f"   {c:32s} {sum(v)/len(v):16.1f}  (n={len(v)})")
