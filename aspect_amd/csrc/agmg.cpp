@@ -257,7 +257,9 @@ struct agmg_ctx {
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                          const std::vector<uint32_t> &send_nodes);
   int build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv);
-  bool use_bricks = true;   // brick kernels on structured 3-D levels (AGMG_NO_BRICKS=1: block / slot path)
+  // brick kernels on structured 3-D levels: parity-green but not yet faster than the block kernels
+  // (DESIGN.md 3.2b), so opt-in: AGMG_BRICKS=1
+  bool use_bricks = false;
   int brick_z_override = 0; // AGMG_BRICK_Z: layers per brick (1, 2, 4 or 8) instead of the size-based choice
   bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && !dist(); }
   int ensure_workspace();
@@ -1857,7 +1859,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   auto *c = new agmg_ctx();
   c->opt = *opt;
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
-  if (const char *e = getenv("AGMG_NO_BRICKS")) c->use_bricks = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_BRICKS")) c->use_bricks = atoi(e) != 0;
   if (const char *e = getenv("AGMG_BRICK_Z")) c->brick_z_override = atoi(e);
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;

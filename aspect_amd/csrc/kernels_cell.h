@@ -133,7 +133,7 @@ template <int DIM> struct WaveXch {
   int lane, j;
   __device__ __forceinline__ void put(int x, int c, int dd, double v) const { (void)c; xb[x][lane * DIM + dd] = v; }
   __device__ __forceinline__ double get(int x, int from, int dir) const { return xb[x][(j * DIM + from) * DIM + dir]; }
-  __device__ __forceinline__ void publish() const {
+  __device__ __forceinline__ void publish() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -150,11 +150,11 @@ template <int DIM> struct WaveXch {
 struct BrickXch {
   static constexpr int TILE = 27 * 64;   // doubles per tile
   double *buf;       // two tiles
-  int lane, parity;
-  __device__ __forceinline__ void put(int x, int c, int dd, double v) const { buf[parity * TILE + ((x * 3 + c) * 3 + dd) * 64 + lane] = v; }
-  __device__ __forceinline__ double get(int x, int from, int dir) const { return buf[parity * TILE + ((x * 3 + from) * 3 + dir) * 64 + lane]; }
-  __device__ __forceinline__ void publish() const { __syncthreads(); }
-  __device__ __forceinline__ void release() { parity ^= 1; }
+  int lane, wpar, rpar;   // tile the next puts go to / the gets come from
+  __device__ __forceinline__ void put(int x, int c, int dd, double v) const { buf[wpar * TILE + ((x * 3 + c) * 3 + dd) * 64 + lane] = v; }
+  __device__ __forceinline__ double get(int x, int from, int dir) const { return buf[rpar * TILE + ((x * 3 + from) * 3 + dir) * 64 + lane]; }
+  __device__ __forceinline__ void publish() { __syncthreads(); wpar ^= 1; }
+  __device__ __forceinline__ void release() { rpar ^= 1; }
 };
 
 // One cell per DIM lanes: gather, sum-factorised evaluate, q-point operation, integrate.
@@ -169,7 +169,8 @@ struct BrickXch {
 // run time by A.nw_on (Newton derivatives, matrix_free_operators.cc:196-213, 249-258: three cell-wide
 // sums over the q-points first, then an extra stress at every q-point) and A.dil_lhs (prescribed
 // dilation, :230-234, 259-268: extra terms in the pressure rows).
-template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN, bool NEWTON = false, class EX = WaveXch<DIM>>
+template <int DIM, int OP, bool COMP, bool PERQ, bool ETA_LDS, bool GATHER, bool GEN, bool NEWTON = false, class EX = WaveXch<DIM>,
+          bool PIPE = false>
 __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, const int c, const int j,
                                              const int lane, EX &ex, double *G,
                                              double *pout, const double *eta_tile, double *u,
@@ -339,18 +340,15 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
   for (int b = 0; b < NP; ++b) pout[b] = 0.0;
 
-  // one batch = one line of three Gauss points along axis 0
-#pragma unroll
-  for (int L = 0; L < NV / 3; ++L) {
-#if !(AGMG_ABLATE & 16)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+  // one batch = one line of three Gauss points along axis 0.  pre: reference derivatives of the line,
+  // physical gradient row of this lane's component, handed to the exchange; post: stress from the
+  // exchanged gradient, transposed derivatives into G.
+  constexpr int NL = NV / 3;
+  using Jac = double[GEN ? 3 : 1][DIM][DIM];   // inverse Jacobians of the line's q-points (general geometry)
+  auto pre = [&](const int L, double (&d)[DIM][3], Jac &Ji) {
     const int qy = (DIM == 3) ? L % 3 : L, qz = (DIM == 3) ? L / 3 : 0;
     const int base = 3 * L;
-    double d[DIM][3];
-    double pq[3], pt[3];
-    double Ji[GEN ? 3 : 1][DIM][DIM];   // inverse Jacobians of the line's q-points (general geometry)
-    if (GEN && !HAS_U) {
+    if (GEN && !HAS_U && !PIPE) {
 #pragma unroll
       for (int x = 0; x < 3; ++x)
 #pragma unroll
@@ -358,19 +356,6 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
           for (int dd = 0; dd < DIM; ++dd)
             Ji[x][e][dd] = A.invJT[((size_t)(base + x) * (DIM * DIM) + e * DIM + dd) * cs + cell];
-    }
-    if (HAS_P) {
-      // Q1 values on this line
-      double t0, t1;
-      if (DIM == 3) {
-        t0 = fma(n1(qy, 0), pz[qz][0], n1(qy, 1) * pz[qz][2]);
-        t1 = fma(n1(qy, 0), pz[qz][1], n1(qy, 1) * pz[qz][3]);
-      } else {
-        t0 = pz[qy][0];
-        t1 = pz[qy][1];
-      }
-#pragma unroll
-      for (int x = 0; x < 3; ++x) pq[x] = fma(n1(x, 0), t0, n1(x, 1) * t1);
     }
     if (HAS_U) {
       // reference-space derivatives (times the Gauss point spacing)
@@ -414,7 +399,24 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
         for (int dd = 0; dd < DIM; ++dd) ex.put(x, c, dd, d[dd][x]);
       }
-      ex.publish();
+    }
+  };
+  auto post = [&](const int L, double (&d)[DIM][3], Jac &Ji) {
+    const int qy = (DIM == 3) ? L % 3 : L, qz = (DIM == 3) ? L / 3 : 0;
+    const int base = 3 * L;
+    double pq[3], pt[3];
+    if (HAS_P) {
+      // Q1 values on this line
+      double t0, t1;
+      if (DIM == 3) {
+        t0 = fma(n1(qy, 0), pz[qz][0], n1(qy, 1) * pz[qz][2]);
+        t1 = fma(n1(qy, 0), pz[qz][1], n1(qy, 1) * pz[qz][3]);
+      } else {
+        t0 = pz[qy][0];
+        t1 = pz[qy][1];
+      }
+#pragma unroll
+      for (int x = 0; x < 3; ++x) pq[x] = fma(n1(x, 0), t0, n1(x, 1) * t1);
     }
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
@@ -462,7 +464,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
             for (int dd = 0; dd < DIM; ++dd) {
               // Stokes runs out of registers holding the line's Jacobians across the exchange: reload (L1 hit)
-              const double jv = (OP == KOP_STOKES && DIM == 3)
+              const double jv = (PIPE || (OP == KOP_STOKES && DIM == 3))
                                     ? A.invJT[((size_t)(base + x) * (DIM * DIM) + e * DIM + dd) * cs + cell]
                                     : Ji[x][e][dd];
               acc = fma(jv, tau[dd], acc);
@@ -526,7 +528,8 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
         for (int e = 0; e < DIM; ++e) {
           double acc = 0.0;
 #pragma unroll
-          for (int dd = 0; dd < DIM; ++dd) acc = fma(Ji[x][e][dd], sel[dd], acc);
+          for (int dd = 0; dd < DIM; ++dd)
+            acc = fma(PIPE ? A.invJT[((size_t)(base + x) * (DIM * DIM) + e * DIM + dd) * cs + cell] : Ji[x][e][dd], sel[dd], acc);
           d[e][x] = (-A.lambda * jxw * INV_S) * pq[x] * acc;
         }
       } else {
@@ -580,6 +583,33 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
       }
 #pragma unroll
       for (int b = 0; b < NP; ++b) asm volatile("" : "+v"(pout[b]) : : "memory");
+    }
+  };
+  if (!PIPE) {
+#pragma unroll
+    for (int L = 0; L < NL; ++L) {
+#if !(AGMG_ABLATE & 16)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      double d[DIM][3];
+      Jac Ji;
+      pre(L, d, Ji);
+      if (HAS_U) ex.publish();
+      post(L, d, Ji);
+    }
+  } else {
+    // software pipeline (two exchange tiles): line L + 1's gradient rows are computed and handed over
+    // between the barrier that publishes line L and the use of line L's exchanged values, so the
+    // barrier skew and the LDS read latency hide under independent arithmetic
+    double dbuf[2][DIM][3];
+    Jac Jd;
+    pre(0, dbuf[0], Jd);
+#pragma unroll
+    for (int L = 0; L < NL; ++L) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (HAS_U) ex.publish();
+      if (L + 1 < NL) pre(L + 1, dbuf[(L + 1) & 1], Jd);
+      post(L, dbuf[L & 1], Jd);
     }
   }
   // Gauss points -> nodes (transposed interpolation), axis by axis

@@ -541,6 +541,7 @@ def test_brick_kernels_layers_per_brick(case, layers, hip_lib, oracle_lib, monke
     level size; AGMG_BRICK_Z forces it): operators on the finest level against the oracle, the compressible
     variants, and a V-cycle + block preconditioner (Chebyshev and residual epilogues on every level that has
     bricks)."""
+    monkeypatch.setenv("AGMG_BRICKS", "1")
     monkeypatch.setenv("AGMG_BRICK_Z", str(layers))
     p = BRICK_CASES[case]().build()
     g, o = capi.Solver(hip_lib, p), capi.Solver(oracle_lib, p)
@@ -570,15 +571,15 @@ def test_brick_kernels_layers_per_brick(case, layers, hip_lib, oracle_lib, monke
 
 
 def test_brick_kernels_equal_block_kernels(hip_lib, monkeypatch):
-    """Same operator through the brick path and through the block path (AGMG_NO_BRICKS=1)."""
+    """Same operator through the brick path (AGMG_BRICKS=1) and through the block path."""
     p = cases.nsinker_box(4, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE)
     p.build_single_level()
     src = rand_vec(p.hier.finest.n_dofs_v + p.hier.finest.n_dofs_p, 3, p.hier.finest)
     out = []
-    for no_bricks in ("0", "1"):
-        monkeypatch.setenv("AGMG_NO_BRICKS", no_bricks)
+    for bricks in ("1", "0"):
+        monkeypatch.setenv("AGMG_BRICKS", bricks)
         g = capi.Solver(hip_lib, p, single_level=True)
-        assert (g.kernel_path()[0] > 0) == (no_bricks == "0")
+        assert (g.kernel_path()[0] > 0) == (bricks == "1")
         out.append(g.vmult(capi.OP_STOKES, src))
         g.close()
     assert relerr(out[0], out[1]) < 1e-13
