@@ -203,17 +203,32 @@ def free_surface_blob(dim, refinement, dt_theta=0.5, deform=None, side_surface=F
         free_surface_spec=dict(boundaries=free, density=rho, gravity=gravity, dt=dt_theta, theta=1.0))
 
 
-def solcx(refinement, averaging=bm.AVG_HARMONIC, jump=1e6, n_cheap=1000):
+def solcx(refinement, averaging=bm.AVG_HARMONIC, jump=1e6, n_cheap=1000, average_density=False):
     """benchmarks/solcx: eta = 1 (x < 1/2) | jump, rho = -sin(pi z) cos(pi x)
-    (solcx.h:2969-2970, 3018); gravity vertical magnitude 1 default; free slip."""
+    (solcx.h:2969-2970, 3018); gravity vertical magnitude 1 default; free slip.
+    average_density: `Material averaging = harmonic average` (tests/no_cheap_gmg.prm:57) averages the
+    density over the cell's q-points too (material_model/interface.cc:542-561, 890-896: unweighted
+    N / sum(1/rho_q), and 0 if any rho_q is exactly 0), unlike `harmonic average only viscosity`."""
 
     def eta(x):
         return np.where(x[:, 0] < 0.5, 1.0, jump)
 
+    def density(x):
+        return -np.sin(np.pi * x[:, 1]) * np.cos(np.pi * x[:, 0])
+
     def force(x):
-        rho = -np.sin(np.pi * x[:, 1]) * np.cos(np.pi * x[:, 0])
         f = np.zeros_like(x)
-        f[:, 1] = -1.0 * rho
+        f[:, 1] = -1.0 * density(x)
+        return f
+
+    def force_q(level):
+        xq = level.qpoint_coords()
+        rho = density(xq.reshape(-1, 2)).reshape(level.n_cells, -1)
+        with np.errstate(divide="ignore"):
+            avg = rho.shape[1] / np.sum(1.0 / rho, axis=1)
+        avg[np.any(rho == 0.0, axis=1)] = 0.0
+        f = np.zeros(rho.shape + (2,))
+        f[:, :, 1] = -1.0 * avg[:, None]
         return f
 
     # pressure scaling: exp(mean log eta)/L with L = 0.01 (helper_functions.cc:286-345)
@@ -221,28 +236,32 @@ def solcx(refinement, averaging=bm.AVG_HARMONIC, jump=1e6, n_cheap=1000):
     return StokesProblem(
         name=f"solcx_r{refinement}", dim=2, refinement=refinement,
         bc=[bm.BC_TANGENTIAL] * 4, eta=eta, force=force, averaging=averaging,
-        pressure_scaling=lam, n_cheap=n_cheap)
+        pressure_scaling=lam, n_cheap=n_cheap, force_q=force_q if average_density else None)
 
 
 def stokes_sinker_box(refinement):
-    """tests/stokes.prm: 3-D isoviscous box 2890 km, free slip, eta = 1e22,
-    rho = 3300 (+100 inside a sphere r = 200 km at the centre), g = 9.81."""
+    """tests/stokes.prm: 3-D isoviscous box 2890 km, free slip, eta = 1e22, `simple` material:
+    rho = 3300 (1 - 2e-5 (T - 293)) + 100 C with T = 0, g = 9.81.  C is the compositional FIELD
+    (Q2, interpolated from the indicator of a sphere r = 200 km at the centre), evaluated at the
+    q-points, not the indicator itself."""
     L = 2890000.0
+    rho0 = 3300.0 * (1.0 + 2e-5 * 293.0)      # "Reference density (kg/m^3): 3319.34" of the golden
 
-    def force(x):
-        r = np.sqrt(((x - 1445000.0) ** 2).sum(axis=1))
-        rho = 3300.0 + np.where(r > 200000.0, 0.0, 100.0)
-        f = np.zeros_like(x)
-        f[:, 2] = -9.81 * rho
+    def force_q(level):
+        xn = level.node_coords_v()
+        c_nodal = np.where(np.sqrt(((xn - 1445000.0) ** 2).sum(axis=1)) > 200000.0, 0.0, 1.0)
+        cq = level.nodal_to_qpoints(c_nodal)
+        f = np.zeros(cq.shape + (3,))
+        f[:, :, 2] = -9.81 * (rho0 + 100.0 * cq)
         return f
 
     def p_static(x):
-        return 3300.0 * 9.81 * (L - x[:, 2])
+        return rho0 * 9.81 * (L - x[:, 2])
 
     return StokesProblem(
         name=f"stokes_sinker_r{refinement}", dim=3, refinement=refinement,
         bc=[bm.BC_TANGENTIAL] * 6, eta=lambda x: np.full(x.shape[0], 1e22),
-        force=force, averaging=bm.AVG_PROJECT_Q1, pressure_scaling=1e22 / (0.01 * L),
+        force=None, force_q=force_q, averaging=bm.AVG_PROJECT_Q1, pressure_scaling=1e22 / (0.01 * L),
         extents=[L, L, L], initial_pressure=p_static)
 
 

@@ -1,0 +1,89 @@
+"""Solution-level quantities the reference's goldens print, computed from a solution vector of the
+C-ABI (velocity, scaled pressure) on a boxmesh level.  Shared by the oracle tests (CPU) and the
+HIP parity tests (GPU)."""
+import os
+
+import numpy as np
+
+from aspect_amd import boxmesh as bm
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _gauss(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return 0.5 * (x + 1.0), 0.5 * w
+
+
+def physical_pressure_surface_normalised(p, x):
+    """p = lambda * p_hat, shifted so that its mean over the top boundary is 0 ('Pressure
+    normalization = surface', Surface pressure = 0; helper_functions.cc:741-927).  2-D boxes."""
+    fin = p.hier.finest
+    pr = p.pressure_scaling * x[fin.n_dofs_v:]
+    assert fin.dim == 2
+    nx, nz = fin.npd
+    top = pr.reshape(nz, nx)[-1]                 # Q1 nodes of the top row (lexicographic numbering)
+    hx = fin.h[0]
+    mean = (0.5 * (top[:-1] + top[1:]) * hx).sum() / (hx * (nx - 1))     # exact for the Q1 trace
+    return pr - mean
+
+
+def solcx_errors(p, x):
+    """u_L1, p_L1, u_L2, p_L2 as benchmarks/solcx/solcx.h:3129-3170 computes them: QGauss(4) per
+    direction, cell-wise errors stored as float, L1 = sum, L2 = sqrt(sum of squares); the L1 norm of a
+    vector-valued error is the integral of the l1 norm of its components (deal.II integrate_difference).
+    Analytic values: tests/golden/solcx_analytic_r*.npy (make_solcx_samples.py)."""
+    fin = p.hier.finest
+    r = p.refinement
+    ref = np.load(os.path.join(GOLDEN, f"solcx_analytic_r{r}.npy"))
+    gx, gw = _gauss(4)
+    N2, N1 = bm.q2_shape(gx), bm.q1_shape(gx)                      # [q][i]
+    S2, S1 = np.kron(N2, N2), np.kron(N1, N1)                      # [q_lex][i_lex], x fastest
+    W = np.kron(gw, gw) * fin.h[0] * fin.h[1]
+    u = x[:fin.n_dofs_v].reshape(-1, 2)
+    pr = physical_pressure_surface_normalised(p, x)
+    n = 1 << r
+    # cells in lexicographic order, as the fixture was written
+    lex_cell = {(int(c[0]), int(c[1])): k for k, c in enumerate(fin.cell_ijk)}
+    e_u1 = np.zeros(n * n, dtype=np.float32); e_p1 = np.zeros_like(e_u1)
+    e_u2 = np.zeros_like(e_u1); e_p2 = np.zeros_like(e_u1)
+    for cz in range(n):
+        for cx in range(n):
+            k = lex_cell[(cx, cz)]
+            rows = ref[(cz * n + cx) * 16:(cz * n + cx + 1) * 16]
+            uq = S2 @ u[fin.cell_nodes_v[k].astype(np.int64)]       # [16][2]
+            pq = S1 @ pr[fin.cell_nodes_p[k].astype(np.int64)]
+            du, dp = uq - rows[:, 2:4], pq - rows[:, 4]
+            c = cz * n + cx
+            e_u1[c] = np.float32((np.abs(du).sum(axis=1) * W).sum())
+            e_p1[c] = np.float32((np.abs(dp) * W).sum())
+            e_u2[c] = np.float32(np.sqrt(((du ** 2).sum(axis=1) * W).sum()))
+            e_p2[c] = np.float32(np.sqrt((dp ** 2 * W).sum()))
+    f = np.float64
+    return (e_u1.astype(f).sum(), e_p1.astype(f).sum(),
+            np.sqrt((e_u2.astype(f) ** 2).sum()), np.sqrt((e_p2.astype(f) ** 2).sum()))
+
+
+def rms_max_velocity(p, x):
+    """'RMS, max velocity' of postprocess/velocity_statistics.cc: sqrt(int |u|^2 / volume) and the
+    largest |u| over the quadrature points, Gauss-3 per direction (quadrature_formulas.velocities)."""
+    fin = p.hier.finest
+    dim = fin.dim
+    u = x[:fin.n_dofs_v].reshape(-1, dim)
+    S = bm.tensor_shape([bm.N2] * dim)
+    W = bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(fin.h)
+    uq = np.einsum("qi,cid->cqd", S, u[fin.cell_nodes_v.astype(np.int64)])
+    m2 = (uq ** 2).sum(axis=2)
+    vol = np.prod(fin.extents)
+    return np.sqrt((m2 * W[None, :]).sum() / vol), np.sqrt(m2.max())
+
+
+def relative_residual_second_iteration(solver, p, x1, rep1):
+    """'Relative nonlinear residual (Stokes system) after nonlinear iteration 2' of the iterated Stokes
+    scheme (solver_schemes.cc:507-527, 910-915): the residual the second solve() finds for the first
+    solve's solution, over the initial residual of the first iteration (helper_functions.cc:1188-1239:
+    the quantity the solver tolerance is a multiple of)."""
+    rhs = np.concatenate([p.rhs_u, p.rhs_p])
+    x2, rep2, rc = solver.solve(rhs=rhs, x0=x1)
+    r0 = rep1.solver_tolerance / p.tol
+    return rep2.initial_nonlinear_residual / r0, rep2

@@ -583,3 +583,92 @@ def test_brick_kernels_equal_block_kernels(hip_lib, monkeypatch):
         out.append(g.vmult(capi.OP_STOKES, src))
         g.close()
     assert relerr(out[0], out[1]) < 1e-13
+
+
+# ---- BASELINE configs[2]: benchmarks/nsinker with its own parameters ------------------------------
+@pytest.mark.parametrize("refinement", [3, 4])
+def test_config3_nsinker_8_sinkers_ratio_1e6(refinement, hip_lib, oracle_lib):
+    """benchmarks/nsinker/nsinker_gmg.prm:20-24, 52-57 as shipped: 8 sinkers, viscosity ratio 1e6
+    (eta in [1e-3, 1e3]), harmonic average of the viscosity only, lambda = 1, tolerance 1e-6, 200 cheap
+    steps, no expensive ones, GMRES(100) -- at the refinements the oracle solves in seconds (the r = 6
+    solve of the config runs in bench.py / tools/config3_iterations.py).  Operators to 1e-12 on the
+    active mesh and every level, GMRES iteration counts within +-1, same solution."""
+    p = cases.nsinker_box(refinement)
+    assert p.tol == 1e-6 and p.n_cheap == 200 and p.n_expensive == 0 and p.restart == 100 and p.pressure_scaling == 1.0
+    g, o = make_pair(p, hip_lib, oracle_lib)
+    assert p.eta_min >= 1e-3 * (1 - 1e-9) and p.eta_max <= 1e3 * (1 + 1e-9) and p.eta_max / p.eta_min > 1e5
+    try:
+        for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT, capi.OP_MASS):
+            for level in [capi.ACTIVE] + list(range(p.hier.n_levels)):
+                lev = p.hier.finest if level == capi.ACTIVE else p.hier.levels[level]
+                src = rand_vec(g.size(which, level), 61 + which, lev, zero_constrained=(which != capi.OP_MASS))
+                assert relerr(g.vmult(which, src, level), o.vmult(which, src, level)) < RTOL, (which, level)
+        xg, rg, rcg = g.solve()
+        xo, ro, rco = o.solve()
+        assert rcg == 0 and rco == 0
+        assert abs(rg.n_cheap_iterations - ro.n_cheap_iterations) <= 1, (rg.n_cheap_iterations, ro.n_cheap_iterations)
+        assert rg.n_expensive_iterations == 0
+        assert rg.n_A_preconditioner_cheap == rg.n_cheap_iterations + -(-rg.n_cheap_iterations // p.restart)
+        nu = p.hier.finest.n_dofs_v
+        rhs = np.concatenate([p.rhs_u, p.rhs_p])
+        assert np.linalg.norm(rhs - o.vmult(capi.OP_STOKES, xg)) <= 1.05 * rg.solver_tolerance
+        # both stop at 1e-6 of the initial residual with a preconditioned system of condition >> 1: the
+        # solutions agree to the error that tolerance leaves
+        assert relerr(xg[:nu], xo[:nu]) < 5e-3
+    finally:
+        g.close(); o.close()
+
+
+# ---- solution-level goldens of the reference, for the HIP solution -----------------------------------
+import json  # noqa: E402
+import os  # noqa: E402
+
+import solution_checks as sc  # noqa: E402
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gmg_goldens.json")))
+
+
+@pytest.mark.parametrize("case,refinement,kw", [
+    ("sol_cx_2_gmg", 2, {}),
+    ("sol_cx_4_gmg", 4, {}),
+    ("sol_cx_4_gmg_no_avg", 4, {"averaging": bm.AVG_NONE}),
+    ("no_cheap_gmg", 4, {"n_cheap": 0, "average_density": True}),
+])
+def test_solcx_goldens_iterations_errors_residual(case, refinement, kw, hip_lib):
+    """tests/<case>/screen-output of the reference against the HIP solve: iteration counts, the four
+    analytic error norms (Errors u_L1, p_L1, u_L2, p_L2) and the relative nonlinear residual of the
+    second nonlinear iteration."""
+    gold = GOLD[case]
+    p = cases.solcx(refinement, **kw).build()
+    s = capi.Solver(hip_lib, p)
+    try:
+        x, rep, rc = s.solve()
+        assert rc == 0
+        assert abs(rep.n_cheap_iterations - gold["solves"][0]["cheap"]) <= 1
+        assert abs(rep.n_expensive_iterations - gold["solves"][0]["expensive"]) <= 1
+        err = sc.solcx_errors(p, x)
+        for got, want in zip(err, gold["errors_uL1_pL1_uL2_pL2"]):
+            assert abs(got / want - 1.0) < 2e-3, (err, gold["errors_uL1_pL1_uL2_pL2"])
+        rel, rep2 = sc.relative_residual_second_iteration(s, p, x, rep)
+        want = gold["nonlinear_residuals"][1]
+        assert rel < p.tol and 1.0 / 3.0 < rel / want < 3.0, (rel, want)
+        assert rep2.n_cheap_iterations == 0 and rep2.n_expensive_iterations == 0
+    finally:
+        s.close()
+
+
+def test_stokes_golden_iterations_and_velocities(hip_lib):
+    """tests/stokes: 8+0 iterations on the first mesh; 'RMS, max velocity' as far as a uniform mesh can
+    pin it (see tests/test_oracle_goldens.py::test_stokes_rms_and_max_velocity)."""
+    p = cases.stokes_sinker_box(2).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0 and abs(rep.n_cheap_iterations - GOLD["stokes"]["solves"][0]["cheap"]) <= 1
+    p = cases.stokes_sinker_box(4).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    rms, vmax = sc.rms_max_velocity(p, x)
+    g_rms, g_max = GOLD["stokes"]["rms_max_velocity"][0]
+    assert rc == 0 and abs(vmax / g_max - 1.0) < 0.15 and 1.0 / 6.0 < rms / g_rms < 6.0, (rms, vmax)
