@@ -2659,6 +2659,50 @@ int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *se
   return rc;
 }
 
+// The in-solver micro-benchmark of the reference ("Execute solver timings", local_smoothing.cc:1234-1375):
+// device-resident, one warm-up call then the mean wall time of n_repeat calls per section, the
+// stream drained on both sides.  seconds[0..5] = stokes_vmult, stokes_preconditioner (cheap),
+// A_preconditioner (one V-cycle), S_preconditioner (one V-cycle), A_block_vmult, setup of the
+// smoothers (eigenvalue estimates of every level, what the reference redoes in every solve()).
+int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
+  if (!c || !seconds || n_repeat < 1) { set_error("bad argument"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  {
+    CHECK(c->sync());
+    const double t0 = now_s();
+    CHECK(c->setup_smoothers());
+    CHECK(c->sync());
+    seconds[5] = now_s() - t0;
+  }
+  const DeviceLevel &lv = c->fin();
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p(), n = nu + np;
+  double *src, *dst;
+  CHECK(c->get_vec(5, &src)); CHECK(c->get_vec(6, &dst));
+  {
+    std::vector<double> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = std::sin(0.37 * (double)i);
+    CHECK(c->h2d(src, h.data(), n));
+    CHECK(vec_zero_constrained(c->stream, src, lv.cmask_v, lv.n_nodes_v, lv.dim));
+  }
+  auto timeit = [&](const std::function<int()> &f, double *out) -> int {
+    CHECK(f());
+    CHECK(c->sync());
+    const double t0 = now_s();
+    for (int i = 0; i < n_repeat; ++i) CHECK(f());
+    CHECK(c->sync());
+    *out = (now_s() - t0) / n_repeat;
+    return 0;
+  };
+  EpiArgs e;
+  e.epi = EPI_STORE; e.dst = dst; e.x = src;
+  CHECK(timeit([&] { return c->stokes_vmult(dst, src); }, &seconds[0]));
+  CHECK(timeit([&] { return c->precondition(false, dst, src, nullptr); }, &seconds[1]));
+  CHECK(timeit([&] { return c->vcycle(0, dst, src); }, &seconds[2]));
+  CHECK(timeit([&] { return c->vcycle(1, dst + nu, src + nu); }, &seconds[3]));
+  CHECK(timeit([&] { return c->apply_level(0, c->nl() - 1, c->active_coeff(), src, e); }, &seconds[4]));
+  return 0;
+}
+
 int agmg_get_level_kernel_path(const agmg_ctx *c, int level, int32_t *n_bricks, int32_t *layers_per_brick, int32_t *n_blocks) {
   if (!c || (level != AGMG_ACTIVE && (level < 0 || level >= (int)c->L.size()))) { set_error("bad level"); return -1; }
   const DeviceLevel &lv = level == AGMG_ACTIVE ? c->L.back() : c->L[level];

@@ -22,6 +22,9 @@ class Ranks:
             kw = {}
             if backend == "nccl" and device is not None:
                 kw["device_id"] = device
+            # a rank that fails before a collective must end the job, not leave the others waiting forever
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("AGMG_DIST_TIMEOUT", "600")))
             dist.init_process_group(backend or "gloo", rank=self.rank, world_size=self.world, **kw)
 
     def barrier(self):

@@ -10,8 +10,9 @@ workload's active mesh with all inputs resident in HBM.  value = (velocity + pre
 whole job) / time per step.  N > 1 (weak scaling): the domain is N unit cubes (2x1x1, 2x2x1,
 2x2x2), one per rank/GPU, each refined like the N = 1 workload; every vmult updates the ghost
 values and compresses the interface sums over RCCL (aspect_amd/parallel.py Transport behind
-agmg_set_communicator).  Should the distributed set-up fail on a node, the ranks fall back to
-independent replicas and the line says so in config.parallelism.
+agmg_set_communicator).  Should the distributed set-up fail on any rank, every rank prints the error
+and exits non-zero: no line is printed (a number from independent replicas would not be a scaling
+number).
 """
 import argparse
 import ctypes as C
@@ -43,16 +44,20 @@ A_FLOP_PER_CELL = 6800.0     # ~6.8 kflop/cell, Cartesian
 
 
 def measured_traffic(refinement, n_cells):
-    """HBM bytes per A-block vmult from the committed PMC passes (profiles/r1_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc.sh, gfx950 correction 2 x FETCH_SIZE,
-    calibrated in profiles/r1_fetch_size_calibration.txt).  bench.py cannot run rocprofv3 on itself,
-    so the number is the last committed measurement of this same workload, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            e = json.load(f)["convection_box_3d"].get(str(refinement))
-        return float(e["traffic_bytes"]) if e and e["n_cells"] == n_cells else None
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per A-block vmult from the committed PMC passes (profiles/r2_traffic.json, else
+    r1_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_traffic.sh, gfx950
+    correction 2 x FETCH_SIZE, calibrated in profiles/r1_fetch_size_calibration.txt).  bench.py cannot
+    run rocprofv3 on itself, so the number is the last committed measurement of this same workload and
+    these same kernels, or None."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                e = json.load(f)["convection_box_3d"].get(str(refinement))
+            if e and e["n_cells"] == n_cells:
+                return float(e["traffic_bytes"])
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
 
 
 def main():
@@ -63,6 +68,8 @@ def main():
     ap.add_argument("--refinement", type=int, default=5, help="configs[1]: convection_box_3d, global refinement 5")
     ap.add_argument("--large-refinement", type=int, default=7,
                     help="extra A-block roofline point on a level that fills the chip (0 = skip)")
+    ap.add_argument("--config3-refinement", type=int, default=6,
+                    help="also solve configs[2] (nsinker, 8 sinkers, ratio 1e6) at this refinement (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -158,10 +165,9 @@ def main():
         except Exception as e:  # noqa: BLE001
             failed, err = 1.0, repr(e)
         if max_over_ranks(failed) > 0:
-            if rank == 0:
-                print(f"[bench] distributed set-up failed ({err}); running independent replicas", file=sys.stderr)
-            prob, solver, fin, src_h, nu, npd = serial_setup()
-            parallelism = f"{world} independent subdomain replicas (distributed set-up failed on this node)"
+            print(f"[bench] rank {rank}: distributed set-up failed ({err or 'on another rank'}); no result", file=sys.stderr)
+            ranks.close()
+            sys.exit(3)
         else:
             parallelism = (f"{world} subdomains (one unit cube per GPU), ghost update + compress per vmult and "
                            f"all-reduce per dot product; transport: {transport_name}")
@@ -203,12 +209,18 @@ def main():
             "bytes_per_cell": algorithmic_bytes_per_cell(nqv)}
 
     # ---------------------------------------------------------------- full solve
-    x, rep, rc = solver.solve(allow_failure=True)      # first call includes smoother setup
-    x, rep2, rc = solver.solve(allow_failure=True)
+    x, rep, rc = solver.solve(allow_failure=True)      # first call: tables of the transfers, smoothers
+    x, rep2, rc = solver.solve(allow_failure=True)     # smoothers cached
     solve_s = max_over_ranks(rep2.solve_seconds)
+    # the reference's own timer sections (local_smoothing.cc:1234-1375) and the smoother set-up that its
+    # solve() redoes every time (:918-1058): "Solve Stokes system" of the reference = setup + solve
+    sections = solver.solver_timings(5)
+    setup_s = max_over_ranks(sections["smoother_setup"])
     extra = {"stokes_vmult_us": 1e6 * t_S, "a_block_vmult_us": 1e6 * t_A,
              "a_block_gdofs": nu / t_A / 1e9,
-             "solve_seconds": solve_s, "solve_setup_seconds": rep.setup_seconds,
+             "solve_seconds": solve_s, "solve_setup_seconds": setup_s,
+             "solve_seconds_including_smoother_setup": solve_s + setup_s,
+             "solver_timings_us": {k: 1e6 * max_over_ranks(v) for k, v in sections.items()},
              "gmres_iterations": f"{rep2.n_cheap_iterations}+{rep2.n_expensive_iterations}",
              "vcycles_A": rep2.n_A_preconditioner_cheap, "vcycles_S": rep2.n_S_preconditioner_cheap,
              "solve_status": rc, "velocity_dofs": int(world * nu), "pressure_dofs": int(world * npd)}
@@ -231,6 +243,21 @@ def main():
                       "fp64_frac": fl.n_cells * A_FLOP_PER_CELL / tl / 1e12 / FP64_PEAK_TFLOPS}
         sl.close()
 
+    # ---------------------------------------------------------------- configs[2]: nsinker, 8 sinkers, ratio 1e6, r6
+    config3 = None
+    if args.config3_refinement and rank == 0 and world == 1:
+        p3 = cases.nsinker_box(args.config3_refinement).build()
+        s3 = capi.Solver(lib, p3, device=local_rank)
+        x3, r3a, rc3 = s3.solve(allow_failure=True)
+        x3, r3b, rc3 = s3.solve(allow_failure=True)
+        t3 = s3.solver_timings(3)
+        config3 = {"workload": f"benchmarks/nsinker r{args.config3_refinement}: 8 sinkers, viscosity ratio 1e6, "
+                               f"{p3.hier.finest.n_cells} cells, {p3.hier.finest.n_dofs_v}+{p3.hier.finest.n_dofs_p} DoFs",
+                   "gmres_iterations": f"{r3b.n_cheap_iterations}+{r3b.n_expensive_iterations}", "solve_status": rc3,
+                   "solve_seconds": r3b.solve_seconds, "solve_seconds_including_smoother_setup": r3b.solve_seconds + t3["smoother_setup"],
+                   "oracle_iterations_r2_r3_r4": "36, 48, 74 (identical on the GPU; profiles/r2_config3_nsinker_iterations.jsonl)"}
+        s3.close()
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -246,9 +273,11 @@ def main():
             o.vmult(capi.OP_STOKES, src_h)
             reps += 1
         tc = (time.perf_counter() - t0) / reps
-        cpu = {"value": n / tc / 1e9, "unit": "GDoF/s", "cores": cores, "kind": "port",
-               "sample": f"{reps} Stokes vmults of the same r{args.refinement} workload by oracle/oracle.cpp "
-                         f"(sum-factorised C++, OpenMP over coloured cells, {cores} threads)"}
+        cpu = {"value": n / tc / 1e9, "unit": "GDoF/s", "cores": cores, "kind": "port", "vectorised": False,
+               "sample": f"{reps} Stokes vmults of the same r{args.refinement} workload by oracle/oracle.cpp: the "
+                         f"UNVECTORISED test oracle (scalar sum-factorisation per cell, no SIMD across cells as "
+                         f"deal.II's VectorizedArray has; OpenMP over coloured cells, {cores} threads). A reported "
+                         f"baseline, not a tuned CPU code: the ratio to it says nothing about kernel quality"}
         o.close()
 
     if rank == 0:
@@ -259,7 +288,7 @@ def main():
                 "config": {"workload": f"cookbooks/convection_box_3d, global refinement {args.refinement}, "
                                        f"{fin.n_cells} cells, {int(nu)}+{int(npd)} DoFs per GPU, per-q viscosity tables",
                            "parallelism": parallelism},
-                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, **extra}
+                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, "config3_nsinker": config3, **extra}
         print(json.dumps(line))
     ranks.close()
 

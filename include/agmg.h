@@ -317,6 +317,14 @@ int agmg_solve(agmg_ctx *ctx, const double *rhs, double *x, int solve_newton_sys
  *   (the in-solver harness local_smoothing.cc:1234-1375). */
 int agmg_bench_vmult(agmg_ctx *ctx, int which, int level, int n_repeat, double *seconds_per_vmult);
 
+/* The reference's in-solver micro-benchmark ("Solver parameters/Matrix Free/Execute solver
+ * timings", local_smoothing.cc:57-62, 1234-1375), device-resident: one warm-up call, then the mean
+ * wall time of n_repeat calls of each section.  seconds[0] stokes_vmult, [1] stokes_preconditioner
+ * (cheap: 2 V-cycles + B^T), [2] A_preconditioner (one V-cycle), [3] S_preconditioner (one V-cycle),
+ * [4] A_block_vmult, [5] set-up of the smoothers (eigenvalue estimates on every level: what the
+ * reference redoes inside every solve(), :918-1058). */
+int agmg_execute_solver_timings(agmg_ctx *ctx, int n_repeat, double seconds[6]);
+
 /* Which kernels apply the velocity-row operators of a level (diagnostics and benchmark reports; the
  * reference's counterpart is the "Output details" block of local_smoothing.cc:1007-1017): bricks of
  * 8 x 8 x layers cells (structured 3-D levels), else blocks of consecutive cells, else (both 0) the
