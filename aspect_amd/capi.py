@@ -93,7 +93,7 @@ SYMBOLS = [
     "default_options", "last_error", "create", "destroy", "set_communicator",
     "rccl_get_unique_id", "set_communicator_rccl", "set_level", "set_coefficients",
     "set_free_surface_faces",
-    "compute_diagonals", "vmult", "vmult_device", "vmult_device_noalloc", "get_inverse_diagonal", "prolongate_add",
+    "compute_diagonals", "rhs_correction", "vmult", "vmult_device", "vmult_device_noalloc", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
     "solve", "bench_vmult", "execute_solver_timings", "get_level_kernel_path", "get_cell_data_memory_consumption",
     "get_mg_transfer_memory_consumption", "get_constraint_memory_consumption",
@@ -143,6 +143,7 @@ class Library:
         self.set_coefficients = fn("set_coefficients", C.c_int, [vp, C.c_int, C.POINTER(CellData)])
         self.set_free_surface_faces = fn("set_free_surface_faces", C.c_int, [vp, C.POINTER(FaceData)])
         self.compute_diagonals = fn("compute_diagonals", C.c_int, [vp])
+        self.rhs_correction = fn("rhs_correction", C.c_int, [vp, c_dp, c_dp])
         self.vmult = fn("vmult", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         self.vmult_device = fn("vmult_device", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
         self.vmult_device_noalloc = fn("vmult_device_noalloc", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
@@ -347,6 +348,14 @@ class Solver:
         f = self.lib.vmult_dense if dense else self.lib.vmult
         self._check(f(self.ctx, which, level, _ptr(dst, C.c_double), _ptr(src, C.c_double)))
         return dst
+
+    def rhs_correction(self, u0, rhs):
+        """correct_stokes_rhs(): rhs - M u0 with u0 read without the constraints."""
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        out = np.ascontiguousarray(rhs, dtype=np.float64).copy()
+        assert u0.size == out.size == self.n_u + self.n_p
+        self._check(self.lib.rhs_correction(self.ctx, _ptr(u0, C.c_double), _ptr(out, C.c_double)))
+        return out
 
     def inverse_diagonal(self, which, level):
         dst = np.zeros(self.size(which, level))

@@ -2459,6 +2459,55 @@ int agmg_vmult(agmg_ctx *c, int which, int level, double *dst, const double *src
   return rc;
 }
 
+// correct_stokes_rhs (local_smoothing.cc:761-898): rhs += -M u0, u0 read without the constraints
+int agmg_rhs_correction(agmg_ctx *c, const double *u0_h, double *rhs_h) {
+  if (!c || !u0_h || !rhs_h) { set_error("null argument"); return -1; }
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  const DeviceLevel &lv = c->fin();
+  if (!lv.set || !c->active_coeff().set) { set_error("rhs_correction: active mesh tables / coefficients not set"); return -1; }
+  CHECK(c->ensure_workspace());
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p(), n = nu + np;
+  double *u0, *rhs;
+  CHECK(c->get_vec(5, &u0)); CHECK(c->get_vec(6, &rhs));
+  CHECK(c->h2d(u0, u0_h, n));
+  CHECK(c->h2d(rhs, rhs_h, n));
+  // no Newton terms, no dilation LHS term; the deviatoric part stays (:835-838)
+  CoeffData cd = c->active_coeff();
+  cd.is_compressible = (cd.is_compressible || cd.dilation) ? 1 : 0;
+  cd.newton = false; cd.dilation = false;
+  EpiArgs eu, ep;
+  eu.epi = ep.epi = EPI_SUB;
+  eu.dst = rhs; ep.dst = rhs + nu;
+  hipStream_t st = c->stream;
+  if (!c->dist()) {
+    CHECK(launch_op_cells(st, lv, cd, AGMG_OP_STOKES, u0, u0 + nu, c->slots_u, c->slots_p, true));
+    CHECK(launch_pull_v(st, lv, c->slots_u, eu));
+    CHECK(launch_pull_p(st, lv, c->slots_p, 1, ep));
+    CHECK(launch_face_term(st, lv.dim, c->faces, lv.cmask_v, u0, rhs, -1.0, nullptr, 0, true));
+  } else {
+    std::vector<agmg_ctx::Msg> m;
+    CHECK(c->add_update(m, lv.xv, u0, lv.xv.nc));
+    CHECK(c->add_update(m, lv.xp, u0 + nu, 1));
+    CHECK(c->exchange(m));
+    CHECK(launch_op_cells(st, lv, cd, AGMG_OP_STOKES, u0, u0 + nu, c->slots_u, c->slots_p, true));
+    CHECK(launch_pull_v(st, lv, c->slots_u, eu, PH_GHOST));
+    CHECK(launch_pull_p(st, lv, c->slots_p, 1, ep, PH_GHOST));
+    m.clear();
+    c->add_compress(m, lv.xv, lv.xv.nc);
+    c->add_compress(m, lv.xp, 1);
+    CHECK(c->exchange(m));
+    CHECK(launch_pull_v(st, lv, c->slots_u, eu, PH_OWNED));
+    CHECK(launch_pull_p(st, lv, c->slots_p, 1, ep, PH_OWNED));
+    if (c->faces.global_active) {
+      if (lv.xv.n_ghost) AGMG_HIP_CHECK(hipMemsetAsync(lv.xv.ghostbuf, 0, (size_t)lv.xv.n_ghost * lv.xv.nc * sizeof(double), st));
+      CHECK(launch_face_term(st, lv.dim, c->faces, lv.cmask_v, u0, rhs, -1.0, lv.xv.ghostbuf, lv.n_owned_v, true));
+      CHECK(c->compress(lv.xv));
+      CHECK(launch_face_add_received(st, lv.dim, c->faces, lv.cmask_v, lv.xv.expbuf, rhs, -1.0));
+    }
+  }
+  return c->d2h(rhs_h, rhs, n);
+}
+
 int agmg_get_inverse_diagonal(agmg_ctx *c, int which, int level, double *dst) {
   if (!c || level < 0 || level >= c->nl()) { set_error("bad level"); return -1; }
   if (!c->diag_ready) { set_error("diagonals not computed"); return -1; }

@@ -47,7 +47,8 @@ enum Epilogue {
   EPI_CHEB = 2,     // dst = (1+f1) x - f1 xold + f2 dinv (b - A x)   (dst may alias xold)
   EPI_ADD = 3,      // dst += sum  (constrained rows untouched)        [restriction]
   EPI_DIAG = 4,     // dst = 1 / (constrained ? 1 : sum)               [inverse diagonal]
-  EPI_DIAG_RAW = 5  // dst = constrained ? 1 : sum
+  EPI_DIAG_RAW = 5, // dst = constrained ? 1 : sum
+  EPI_SUB = 6       // dst -= sum  (constrained rows untouched)        [right-hand side correction]
 };
 
 struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
@@ -187,8 +188,9 @@ struct EpiArgs {
 // cell kernels write per-cell contributions to `slots`; pull kernels sum them per DoF.
 // which: AGMG_OP_STOKES (reads u,p; writes slots_u, slots_p), AGMG_OP_A (u -> slots_u),
 // AGMG_OP_BT (p -> slots_u)
+// plain: read the source without the constraints (right-hand side correction)
 int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which,
-                    const double *src_u, const double *src_p, double *slots_u, double *slots_p);
+                    const double *src_u, const double *src_p, double *slots_u, double *slots_p, bool plain = false);
 int launch_mass_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p,
                       double *slots_p);
 int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, double *slots_u,
@@ -226,7 +228,7 @@ struct FaceTerm {
 // (distributed): the sums of ghost nodes (index >= n_owned) go, unsigned, to
 // ghost_out[(node - n_owned) * dim + c] for the compress step instead.
 int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *src_u,
-                     double *dst_u, double sign, double *ghost_out = nullptr, int n_owned = 0);
+                     double *dst_u, double sign, double *ghost_out = nullptr, int n_owned = 0, bool plain = false);
 // dst_u[node] += sign * (sum of the node's receive-buffer entries), fixed order, unconstrained rows
 int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *recv,
                              double *dst_u, double sign);

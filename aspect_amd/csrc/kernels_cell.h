@@ -98,6 +98,9 @@ struct CellArgs {
   // prescribed dilation (Stokes operator, active level): LHS term [q][cstride]; with Newton
   // derivatives d/d(strain rate) [q][NS][cstride] and d/dp [q][cstride] (or nullptr)
   const double *dil_lhs, *dil_de, *dil_dp;
+  // 1: read the source WITHOUT the constraints (FEEvaluation::read_dof_values_plain): the right-hand
+  // side correction for inhomogeneous boundary values (local_smoothing.cc:813, 817)
+  int plain;
 };
 
 enum { KOP_STOKES = 0, KOP_A = 1, KOP_BT = 2 };
@@ -219,7 +222,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #else
       const double v = A.src_u[(size_t)(idx & NODE_MASK) * DIM + c];
 #endif
-      u[a] = ((idx >> (29 + c)) & 1u) ? 0.0 : v;
+      u[a] = (((idx >> (29 + c)) & 1u) && !A.plain) ? 0.0 : v;
     }
   }
   if (HAS_U) {
@@ -244,7 +247,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
     for (int b = 0; b < NP; ++b) {
       const uint32_t idx = A.cnpT[b * cs + cell];
       const double v = A.src_p[idx & NODE_MASK];
-      pin[b] = ((idx >> 29) & 1u) ? 0.0 : v;
+      pin[b] = (((idx >> 29) & 1u) && !A.plain) ? 0.0 : v;
     }
 #pragma unroll
     for (int z = 0; z < 3; ++z)
@@ -661,6 +664,10 @@ __device__ __forceinline__ bool epi_value(const EpiArgs &e, const size_t t, cons
       if (con) return false;
       out = e.dst[t] + sum;
       return true;
+    case EPI_SUB:
+      if (con) return false;
+      out = e.dst[t] - sum;
+      return true;
     case EPI_DIAG:
       out = 1.0 / (con ? 1.0 : sum);
       return true;
@@ -727,6 +734,7 @@ inline CellArgs make_cell_args(const DeviceLevel &L, const CoeffData &cd, const 
   a.dil_lhs = cd.dilation ? cd.dil_lhs : nullptr;
   a.dil_de = cd.dil_de;
   a.dil_dp = cd.dil_dp;
+  a.plain = 0;
   return a;
 }
 

@@ -746,7 +746,8 @@ __global__ void __launch_bounds__(256) k_fix_pull(const FixArgs F, const PullArg
 template <int DIM>
 __global__ void __launch_bounds__(128) k_face_term(const FaceTerm F, const uint8_t *__restrict__ cmask,
                                                    const double *__restrict__ src, double *__restrict__ dst,
-                                                   const double sign, double *__restrict__ ghost_out, const int n_owned) {
+                                                   const double sign, double *__restrict__ ghost_out, const int n_owned,
+                                                   const int plain) {
   constexpr int NF = DIM == 3 ? 9 : 3, NQF = NF;
   const int s = blockIdx.x * 128 + threadIdx.x;
   if (s >= F.n_nodes) return;
@@ -769,7 +770,7 @@ __global__ void __launch_bounds__(128) k_face_term(const FaceTerm F, const uint8
       const uint32_t nb = F.fnode[(size_t)f * NF + b];
       const uint8_t m = cmask[nb];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) u[b][c] = ((m >> c) & 1) ? 0.0 : src[(size_t)nb * DIM + c];
+      for (int c = 0; c < DIM; ++c) u[b][c] = (((m >> c) & 1) && !plain) ? 0.0 : src[(size_t)nb * DIM + c];
     }
 #pragma unroll
     for (int q = 0; q < NQF; ++q) {
@@ -886,11 +887,11 @@ int launch_blk_op(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiA
 }  // namespace
 
 int launch_face_term(hipStream_t s, int dim, const FaceTerm &ft, const uint8_t *cmask_v, const double *src_u,
-                     double *dst_u, double sign, double *ghost_out, int n_owned) {
+                     double *dst_u, double sign, double *ghost_out, int n_owned, bool plain) {
   if (ft.n_nodes <= 0) return 0;
   const dim3 grid((ft.n_nodes + 127) / 128), block(128);
-  if (dim == 3) hipLaunchKernelGGL((k_face_term<3>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign, ghost_out, n_owned);
-  else hipLaunchKernelGGL((k_face_term<2>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign, ghost_out, n_owned);
+  if (dim == 3) hipLaunchKernelGGL((k_face_term<3>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign, ghost_out, n_owned, plain ? 1 : 0);
+  else hipLaunchKernelGGL((k_face_term<2>), grid, block, 0, s, ft, cmask_v, src_u, dst_u, sign, ghost_out, n_owned, plain ? 1 : 0);
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -906,10 +907,11 @@ int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const u
 
 
 int launch_op_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
-                    const double *src_p, double *slots_u, double *slots_p) {
+                    const double *src_p, double *slots_u, double *slots_p, bool plain) {
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
-  const CellArgs a = make_cell_args(L, cd, src_u, src_p, slots_u, slots_p);
+  CellArgs a = make_cell_args(L, cd, src_u, src_p, slots_u, slots_p);
+  a.plain = plain ? 1 : 0;
   const bool perq = cd.nqv > 1;
   // the compressible term only exists where the velocity is read (A, Stokes)
   const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;

@@ -266,6 +266,15 @@ int agmg_vmult(agmg_ctx *ctx, int which, int level, double *dst, const double *s
 /* same on device pointers, asynchronous on the context's stream */
 int agmg_vmult_device(agmg_ctx *ctx, int which, int level, double *dst, const double *src);
 
+/* correct_stokes_rhs() (local_smoothing.cc:761-898): rhs += -M u0 on the active mesh, host vectors
+ * [n_dofs_v + n_dofs_p].  u0 is the zero vector with the inhomogeneous boundary values distributed
+ * (constraints.distribute(u0), :775-787); it is read WITHOUT the constraints
+ * (read_dof_values_plain, :813, 817); rows of constrained DoFs receive nothing
+ * (integrate_scatter); no Newton terms; compressible / dilation models keep the
+ * deviatoric term only (:835-838); free-surface faces with plain reads (:853-888).
+ * Call after agmg_set_coefficients(AGMG_ACTIVE or the finest level) once per assemble. */
+int agmg_rhs_correction(agmg_ctx *ctx, const double *u0, double *rhs);
+
 /* agmg_vmult_device for callers that cannot allocate: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart
  * in the reference.  Same arguments and results as agmg_vmult_device; the slot /

@@ -1454,6 +1454,62 @@ int do_solve(Ctx &C, const double *rhs_in, double *x_io, int newton, agmg_solve_
 }  // namespace
 
 // ====================================================================== C API
+// correct_stokes_rhs (local_smoothing.cc:761-898): rhs += -M u0 with u0 read WITHOUT the constraints
+// (read_dof_values_plain, :813, 817), no Newton terms, no dilation LHS term (only the deviatoric part,
+// :835-838); integrate_scatter drops the rows of constrained DoFs; the face term of the free-surface
+// stabilisation likewise with plain reads (:853-888).
+template <int DIM>
+static void rhs_correction_impl(Ctx &C, const double *u0, double *rhs) {
+  const Level &L = C.fin();
+  CellData cd = C.active_cd.set ? C.active_cd : L.cd;
+  cd.is_compressible = cd.is_compressible || cd.dilation;
+  cd.newton = 0; cd.dilation = 0;
+  const int NV = L.nv, NP = L.np, nu = L.ndv();
+  const double *su = u0, *sp = u0 + nu;
+  double *ru = rhs, *rp = rhs + nu;
+  for (int cell = 0; cell < L.n_cells; ++cell) {
+    double uin[3][27], pin[8], uout[3][27], pout[8];
+    const uint32_t *nv = &L.cnv[size_t(cell) * NV];
+    const uint32_t *np = &L.cnp[size_t(cell) * NP];
+    for (int i = 0; i < NV; ++i)
+      for (int c = 0; c < DIM; ++c) uin[c][i] = su[size_t(nv[i]) * DIM + c];
+    for (int i = 0; i < NP; ++i) pin[i] = sp[np[i]];
+    cell_apply<DIM>(L, cd, cell, M_STOKES, uin, pin, uout, pout);
+    for (int i = 0; i < NV; ++i)
+      for (int c = 0; c < DIM; ++c)
+        if (!L.constrained_v(nv[i], c)) ru[size_t(nv[i]) * DIM + c] -= uout[c][i];
+    for (int i = 0; i < NP; ++i)
+      if (!L.constrained_p(np[i])) rp[np[i]] -= pout[i];
+  }
+  if (cd.n_faces) {   // face_terms() with plain reads
+    constexpr int NF = DIM == 3 ? 9 : 3, NQF = NF;
+    for (int f = 0; f < cd.n_faces; ++f) {
+      const uint32_t *nv = &L.cnv[size_t(cd.face_cell[f]) * L.nv];
+      int node[NF];
+      double u[NF][DIM], out[NF][DIM];
+      for (int a = 0; a < NF; ++a) {
+        node[a] = nv[face_node_local<DIM>(cd.face_no[f], a)];
+        for (int c = 0; c < DIM; ++c) { u[a][c] = su[size_t(node[a]) * DIM + c]; out[a][c] = 0.0; }
+      }
+      for (int q = 0; q < NQF; ++q) {
+        double shape[NF];
+        for (int a = 0; a < NF; ++a) shape[a] = DIM == 3 ? T.N2[q % 3][a % 3] * T.N2[q / 3][a / 3] : T.N2[q][a];
+        double n[3], jxw, gu = 0.0;
+        face_geometry<DIM>(L, cd, f, q, n, jxw);
+        for (int c = 0; c < DIM; ++c) {
+          double uq = 0.0;
+          for (int a = 0; a < NF; ++a) uq += shape[a] * u[a][c];
+          gu += cd.face_stab[(size_t(f) * NQF + q) * DIM + c] * uq;
+        }
+        for (int a = 0; a < NF; ++a)
+          for (int c = 0; c < DIM; ++c) out[a][c] += shape[a] * (-gu * n[c]) * jxw;
+      }
+      for (int a = 0; a < NF; ++a)
+        for (int c = 0; c < DIM; ++c)
+          if (!L.constrained_v(node[a], c)) ru[size_t(node[a]) * DIM + c] -= out[a][c];
+    }
+  }
+}
 struct oracle_ctx { Ctx c; };
 
 extern "C" {
@@ -1595,6 +1651,11 @@ static void vmult_impl(Ctx &C, int which, int level, double *dst, const double *
     else op_vmult<3>(L, cd, which == AGMG_OP_BT ? M_BT : M_STOKES, src, src + nu, dst, dst + nu);
   }
 }
+int oracle_rhs_correction(oracle_ctx *o, const double *u0, double *rhs) {
+  if (o->c.opt.dim == 2) rhs_correction_impl<2>(o->c, u0, rhs); else rhs_correction_impl<3>(o->c, u0, rhs);
+  return 0;
+}
+
 int oracle_vmult(oracle_ctx *o, int which, int level, double *dst, const double *src) { vmult_impl(o->c, which, level, dst, src, false); return 0; }
 int oracle_vmult_dense(oracle_ctx *o, int which, int level, double *dst, const double *src) { vmult_impl(o->c, which, level, dst, src, true); return 0; }
 

@@ -672,3 +672,28 @@ def test_stokes_golden_iterations_and_velocities(hip_lib):
     rms, vmax = sc.rms_max_velocity(p, x)
     g_rms, g_max = GOLD["stokes"]["rms_max_velocity"][0]
     assert rc == 0 and abs(vmax / g_max - 1.0) < 0.15 and 1.0 / 6.0 < rms / g_rms < 6.0, (rms, vmax)
+
+
+@pytest.mark.parametrize("case", ["nsinker_r3_harmonic", "box3d_r2_freeslip", "deformed3d_r2_harmonic", "solcx_r2",
+                                  "free_surface_2d", "free_surface_3d_deformed"])
+def test_rhs_correction(case, hip_lib, oracle_lib):
+    """agmg_rhs_correction = correct_stokes_rhs (local_smoothing.cc:761-898) against the oracle: u0 with
+    non-zero entries on the constrained DoFs (inhomogeneous boundary values), also compressible and with
+    free-surface faces."""
+    extra = {"free_surface_2d": lambda: cases.free_surface_blob(2, 3),
+             "free_surface_3d_deformed": lambda: cases.free_surface_blob(3, 2, deform=lambda x: x + 0.02 * np.sin(2 * x[:, ::-1] + 0.5))}
+    p = (PROBLEMS.get(case) or extra[case])()
+    g, o = make_pair(p, hip_lib, oracle_lib)
+    try:
+        rng = np.random.Generator(np.random.PCG64(23))
+        n = g.size(capi.OP_STOKES)
+        for comp in (0, 1):
+            if comp:
+                for s in (g, o):
+                    s._set_coeff(capi.ACTIVE, p.eta_active, is_compressible=1)
+            u0, rhs = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+            a, b = g.rhs_correction(u0, rhs), o.rhs_correction(u0, rhs)
+            assert relerr(a, b) < RTOL, (case, comp, relerr(a, b))
+            assert relerr(a, rhs) > 1e-3          # something was subtracted
+    finally:
+        g.close(); o.close()

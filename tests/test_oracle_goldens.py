@@ -353,3 +353,38 @@ def test_stokes_rms_and_max_velocity():
     g_rms, g_max = G["stokes"]["rms_max_velocity"][0]
     assert abs(vmax / g_max - 1.0) < 0.15, (vmax, g_max)
     assert 1.0 / 6.0 < rms / g_rms < 6.0, (rms, g_rms)
+
+
+def test_rhs_correction_equals_unconstrained_operator():
+    """correct_stokes_rhs (local_smoothing.cc:761-898): rhs += -M u0 with u0 read without the
+    constraints and constrained rows dropped.  Parity unpinned by a reference number here (its golden,
+    tests/hollow_sphere_gmg, needs the shell mesh); pinned by construction: the same cells with NO
+    boundary conditions give the unconstrained operator, whose rows of unconstrained DoFs must agree."""
+    for make, kw in ((lambda: cases.nsinker_box(2, n_sinkers=4, ratio=1e4), {}),
+                     (lambda: cases.deformed_sinker_box(3, 2), {}),
+                     (lambda: cases.solcx(3), {"is_compressible": 1})):
+        p1, p2 = make().build(), make()
+        p2.bc = [bm.BC_NONE] * len(p2.bc)
+        p2.build()
+        s1, s2 = pyoracle.solver(p1), pyoracle.solver(p2)
+        if kw:
+            for s, p in ((s1, p1), (s2, p2)):
+                for l in range(p.hier.n_levels):
+                    s._set_coeff(l, p.eta_levels[l], **kw)
+                s._set_coeff(capi.ACTIVE, p.eta_active, **kw)
+        fin = p1.hier.finest
+        rng = np.random.Generator(np.random.PCG64(5))
+        u0 = rng.uniform(-1, 1, fin.n_dofs_v + fin.n_dofs_p)
+        rhs = rng.uniform(-1, 1, u0.size)
+        got = s1.rhs_correction(u0, rhs)
+        want = rhs - s2.vmult(capi.OP_STOKES, u0)
+        con = np.concatenate([fin.constrained_dofs_v(), np.zeros(fin.n_dofs_p, dtype=bool)])
+        want[con] = rhs[con]
+        assert np.linalg.norm(got - want) <= 1e-13 * np.linalg.norm(want)
+        # u0 that vanishes on the constrained DoFs: plain read = constrained read
+        u0[con] = 0.0
+        got = s1.rhs_correction(u0, np.zeros_like(u0))
+        want = -s1.vmult(capi.OP_STOKES, u0)
+        want[con] = 0.0
+        assert np.linalg.norm(got - want) <= 1e-13 * np.linalg.norm(want)
+        s1.close(); s2.close()
