@@ -699,19 +699,59 @@ struct FixArgs {
   int n_owned;
   EpiArgs e;
 };
+// One thread per shared node.  The loads are arranged in three dependent rounds instead of one
+// per CSR entry: (row bounds, node word) -> (the first FIX_PRE list entries, clamped) + the
+// epilogue's operands (they only need the node) -> the partial sums; rows with more entries finish
+// in a loop.  The order of the additions is the CSR order as before: bitwise the same sums.
 template <int NC>
 __device__ __forceinline__ void fix_body(const FixArgs &F, const unsigned block) {
+  constexpr int FIX_PRE = 4;
   const int il = (int)block * 256 + threadIdx.x;
   if (il >= F.n_range) return;
   const int i = F.i0 + il;
   const uint32_t s = F.sh_ptr[i], en = F.sh_ptr[i + 1];
   const uint32_t nd = F.sh_nodes[i];   // node | cmask << 29
+  const size_t g0 = (size_t)(nd & NODE_MASK) * NC;
+  uint32_t ent[FIX_PRE];
+#pragma unroll
+  for (int k = 0; k < FIX_PRE; ++k) ent[k] = F.sh_list[min(s + k, en - 1)];
+  // epilogue operands of this node (velocity-row epilogues: STORE / RESID / CHEB; others load later)
+  const EpiArgs &E = F.e;
+  const bool pre = !F.ghost_out && (E.epi == EPI_STORE || E.epi == EPI_RESID || E.epi == EPI_CHEB);
+  double xv[NC], bv[NC], dv[NC], ov[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    xv[c] = bv[c] = dv[c] = ov[c] = 0.0;
+    if (pre) {
+      const bool con = (nd >> (29 + c)) & 1u;
+      if (E.epi == EPI_CHEB) {
+        xv[c] = E.x[g0 + c]; bv[c] = E.b[g0 + c]; dv[c] = E.dinv[g0 + c];
+        if (E.xold) ov[c] = E.xold[g0 + c];
+      } else {
+        if (con && E.x) xv[c] = E.x[g0 + c];
+        if (E.epi == EPI_RESID) bv[c] = E.b[g0 + c];
+      }
+    }
+  }
+  double part[FIX_PRE][NC];
+#pragma unroll
+  for (int k = 0; k < FIX_PRE; ++k) {
+    const double *p = ent[k] >= F.recv_base ? F.recv + (size_t)(ent[k] - F.recv_base) * NC : F.slots_sh + (size_t)ent[k] * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[k][c] = p[c];
+  }
   double sum[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) sum[c] = 0.0;
-  for (uint32_t k = s; k < en; ++k) {
-    const uint32_t ent = F.sh_list[k];
-    const double *p = ent >= F.recv_base ? F.recv + (size_t)(ent - F.recv_base) * NC : F.slots_sh + (size_t)ent * NC;
+#pragma unroll
+  for (int k = 0; k < FIX_PRE; ++k)
+    if (s + k < en) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sum[c] += part[k][c];
+    }
+  for (uint32_t k = s + FIX_PRE; k < en; ++k) {
+    const uint32_t e = F.sh_list[k];
+    const double *p = e >= F.recv_base ? F.recv + (size_t)(e - F.recv_base) * NC : F.slots_sh + (size_t)e * NC;
 #pragma unroll
     for (int c = 0; c < NC; ++c) sum[c] += p[c];
   }
@@ -721,7 +761,24 @@ __device__ __forceinline__ void fix_body(const FixArgs &F, const unsigned block)
     for (int c = 0; c < NC; ++c) o[c] = sum[c];
     return;
   }
-  const size_t g0 = (size_t)(nd & NODE_MASK) * NC;
+  if (pre) {
+    double out[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool con = (nd >> (29 + c)) & 1u;
+      const double Ax = con ? xv[c] : sum[c];
+      if (E.epi == EPI_STORE) out[c] = Ax;
+      else if (E.epi == EPI_RESID) out[c] = bv[c] - Ax;
+      else {
+        double v = fma(E.f2 * dv[c], bv[c] - Ax, (1.0 + E.f1) * xv[c]);
+        if (E.xold) v = fma(-E.f1, ov[c], v);
+        out[c] = v;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) E.dst[g0 + c] = out[c];
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const bool con = (nd >> (29 + c)) & 1u;
