@@ -12,6 +12,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+import os
+
 from . import boxmesh as bm
 
 # first 8 of the 75 sinker centres, benchmarks/nsinker/nsinker.cc:203-210
@@ -65,10 +67,19 @@ class StokesProblem:
     free_surface_spec: dict = None
     free_surface: tuple = field(default=None, repr=False)
     hier: bm.BoxHierarchy = field(default=None, repr=False)
+    make_hierarchy: callable = None     # (refinement, only_finest) -> hierarchy (other geometries than the box)
+    pressure_scaling_from_mesh: callable = None   # finest level -> lambda (helper_functions.cc:252-350)
+
+    def _hierarchy(self, only_finest):
+        if self.make_hierarchy is not None:
+            return self.make_hierarchy(self.refinement, only_finest)
+        return bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc, only_finest=only_finest,
+                               deform=self.deform, periodic=self.periodic, numbering=self.numbering)
 
     def build(self):
-        self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    deform=self.deform, periodic=self.periodic, numbering=self.numbering)
+        self.hier = self._hierarchy(False)
+        if self.pressure_scaling_from_mesh is not None:
+            self.pressure_scaling = self.pressure_scaling_from_mesh(self.hier.finest)
         self.eta_active, self.eta_levels, self.eta_min, self.eta_max = \
             bm.viscosity_tables(self.hier, self.eta, self.averaging)
         fin = self.hier.finest
@@ -104,9 +115,10 @@ class StokesProblem:
 
     def build_single_level(self):
         """Only the active mesh (operator benchmarks on big levels: no hierarchy, no RHS)."""
-        self.hier = bm.BoxHierarchy(self.dim, self.refinement, self.extents, self.reps, self.bc,
-                                    only_finest=True, deform=self.deform, periodic=self.periodic, numbering=self.numbering)
+        self.hier = self._hierarchy(True)
         fin = self.hier.finest
+        if self.pressure_scaling_from_mesh is not None:
+            self.pressure_scaling = self.pressure_scaling_from_mesh(fin)
         nq = 3 ** self.dim
         if self.averaging == bm.AVG_HARMONIC:
             eta_q = self.eta(fin.qpoint_coords().reshape(-1, self.dim)).reshape(fin.n_cells, nq)
@@ -337,3 +349,62 @@ def periodic_box_2d(refinement=5, no_slip_walls=False):
         eta=lambda x: np.full(x.shape[0], 1e20), force=None, force_q=force_q,
         averaging=bm.AVG_HARMONIC, pressure_scaling=1e20 / (0.01 * X), extents=[X, Y],
         periodic=[True, False], tol=1e-8, n_cheap=100, n_expensive=1000, initial_pressure=p_static)
+
+
+NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
+
+
+def nsinker_shell(refinement, n_sinkers=5, ratio=1e2, jump=100.0, averaging="harmonic average",
+                  tol=1e-6, restart=200, n_cheap=2000, n_expensive=0):
+    """benchmarks/nsinker_spherical_shell/gmg.prm + nsinker.cc (BASELINE configs[3]): shell R in
+    [0.54, 1], zero velocity on both spheres, radial gravity of magnitude 1, the 75 sinker centres of
+    the box benchmark mapped c -> 2c - 1 with those outside the shell removed (order kept,
+    nsinker.cc:285-296), delta = 400, omega = 0.2 (:204-205), viscosity x `jump` below r = 0.89583
+    (:62-63); `Material averaging = harmonic average` averages the density too."""
+    from . import shellmesh as sm
+    sr = np.sqrt(ratio)
+    c = 2.0 * NSINKER_ALL_CENTERS - 1.0
+    nrm = np.linalg.norm(c, axis=1)
+    centers = c[(nrm >= 0.54) & (nrm <= 1.0)][:n_sinkers]
+    assert centers.shape[0] == n_sinkers
+
+    def chi(x):
+        out = np.ones(x.shape[0])
+        for s_ in range(n_sinkers):
+            d = np.sqrt(((x - centers[s_][None, :]) ** 2).sum(axis=1))
+            t = np.maximum(0.0, d - 0.2 / 2)
+            out *= 1.0 - np.exp(-400.0 * t * t)
+        return out
+
+    def eta(x):
+        e = (sr - 1.0 / sr) * (1.0 - chi(x)) + 1.0 / sr
+        return np.where(np.linalg.norm(x, axis=1) < 0.89583, e * jump, e)
+
+    def density(x):
+        return 10.0 * (1.0 - chi(x))
+
+    def force_q(level):
+        xq = level.qpoint_coords()
+        flat = xq.reshape(-1, 3)
+        rho = density(flat).reshape(level.n_cells, -1)
+        if averaging == "harmonic average":       # density averaged too; 0 if any value is exactly 0
+            with np.errstate(divide="ignore"):
+                avg = rho.shape[1] / np.sum(1.0 / rho, axis=1)
+            avg[np.any(rho == 0.0, axis=1)] = 0.0
+            rho = np.broadcast_to(avg[:, None], rho.shape)
+        rhat = flat / np.linalg.norm(flat, axis=1, keepdims=True)
+        return (-1.0 * rho.reshape(-1)[:, None] * rhat).reshape(xq.shape)     # gravity points inwards
+
+    def scaling(fin):
+        # exp(volume mean of log eta at the cell mid-points) / L, L = 1e4 / 2855000 * (R1 - R0)
+        # (helper_functions.cc:286-345, spherical_shell.cc:665-676); mid-point rule weights = cell volumes
+        le = np.log(eta(fin.cell_centers()))
+        vol = fin.jxw.sum(axis=1)
+        return float(np.exp((le * vol).sum() / vol.sum()) / (1e4 / (6336000.0 - 3481000.0) * (1.0 - 0.54)))
+
+    return StokesProblem(
+        name=f"nsinker_shell_r{refinement}", dim=3, refinement=refinement, bc=None, eta=eta, force=None,
+        force_q=force_q, averaging=bm.AVG_HARMONIC, pressure_scaling=1.0, tol=tol, restart=restart,
+        n_cheap=n_cheap, n_expensive=n_expensive,
+        make_hierarchy=lambda r, only_finest: sm.ShellHierarchy(r, 0.54, 1.0, zero_velocity=True, only_finest=only_finest),
+        pressure_scaling_from_mesh=scaling)

@@ -204,6 +204,11 @@ struct agmg_ctx {
   }
 
   int nl() const { return (int)L.size(); }
+  // level 0 lives on the host (dense operator + Jacobi-Chebyshev) while it is small: one coarse cell
+  // per tree of a box is 81 + 8 DoFs; the 96-cell shell (2910 + 150) would spend the V-cycle in a
+  // 2910^2 host matvec, so larger coarse levels run the same smoother on the device
+  static constexpr size_t COARSE_HOST_MAX_DOFS = 600;
+  bool coarse_host(int which) const { return opt.coarse_on_host && !dist() && size_of(which, 0) <= COARSE_HOST_MAX_DOFS; }
   DeviceLevel &fin() { return L.back(); }
   const CoeffData &active_coeff() { return active.set ? active : fin().coeff; }
   size_t size_of(int which, int l) const { return which == 0 ? (size_t)L[l].n_dofs_v() : (size_t)L[l].n_dofs_p(); }
@@ -1023,7 +1028,7 @@ int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
 
 // level 0: MGCoarseGridApplySmoother = smoother apply (local_smoothing.cc:999-1004)
 int agmg_ctx::coarse_solve(int which) {
-  if (!opt.coarse_on_host || dist()) return smoother_apply(which, 0, mg_def[which][0]);
+  if (!coarse_host(which)) return smoother_apply(which, 0, mg_def[which][0]);
   const CoarseOp &co = coarse[which];
   const Smoother &s = sm[which][0];
   const int n = co.n, steps = which == 0 ? 1 : opt.schur_smoother_steps;
@@ -1351,7 +1356,7 @@ int agmg_ctx::setup_smoothers() {
   std::vector<std::pair<int, int>> batch;
   for (int w = 0; w < 2; ++w)
     for (int l = 0; l < nl(); ++l) {
-      if (l == 0 && opt.coarse_on_host && !dist()) CHECK(build_coarse(w));
+      if (l == 0 && coarse_host(w)) CHECK(build_coarse(w));
       else if (!dist() && use_batched_setup) batch.emplace_back(w, l);
       else CHECK(estimate_device(w, l));
     }

@@ -11,7 +11,8 @@ import sys
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", "nsinker_gmg_idr",
          "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
-         "particle_interpolator_bilinear_3d", "periodic_box_gmg"]
+         "particle_interpolator_bilinear_3d", "periodic_box_gmg", "nsinker_gmg_gc"]
+SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 
 def parse(path):
@@ -69,6 +70,12 @@ def main():
         res[c] = parse(os.path.join(REF, "tests", c, "screen-output"))
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gmg_goldens.json")
     json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+    print("wrote", dst)
+    shell = {"_source": res["_source"]}
+    for c in SHELL_CASES:
+        shell[c] = parse(os.path.join(REF, "tests", c, "screen-output"))
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shell_goldens.json")
+    json.dump(shell, open(dst, "w"), indent=1, sort_keys=True)
     print("wrote", dst)
 
 

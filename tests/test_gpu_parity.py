@@ -697,3 +697,40 @@ def test_rhs_correction(case, hip_lib, oracle_lib):
             assert relerr(a, rhs) > 1e-3          # something was subtracted
     finally:
         g.close(); o.close()
+
+
+# ---- BASELINE configs[3]: benchmarks/nsinker_spherical_shell on the 96-cell shell ---------------------
+def test_config4_nsinker_spherical_shell(hip_lib, oracle_lib):
+    """General (degree-4 mapping) Jacobians in every kernel on the real shell geometry, 96 trees with
+    different orientations, zero velocity on both spheres, the deck's material (5 sinkers, ratio 100,
+    jump 100 below r = 0.89583, harmonic average of viscosity and density), pressure scaling from the
+    mesh, tolerance 1e-6, GMRES(200): operators to 1e-12 on every level, the inverse diagonals, the
+    right-hand side correction, and the solve (same number of iterations to 2 x tolerance as the
+    oracle, see tests/test_oracle_goldens.py::test_shell_operators_dense_and_solve for why not to the
+    tolerance itself; then convergence to the tolerance)."""
+    p = cases.nsinker_shell(1)
+    g, o = make_pair(p, hip_lib, oracle_lib)
+    try:
+        for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT, capi.OP_MASS):
+            for level in [capi.ACTIVE] + list(range(p.hier.n_levels)):
+                lev = p.hier.finest if level == capi.ACTIVE else p.hier.levels[level]
+                src = rand_vec(g.size(which, level), 71 + which, lev, zero_constrained=(which != capi.OP_MASS))
+                assert relerr(g.vmult(which, src, level), o.vmult(which, src, level)) < RTOL, (which, level)
+        for level in range(p.hier.n_levels):
+            for which in (capi.OP_A, capi.OP_MASS):
+                assert relerr(g.inverse_diagonal(which, level), o.inverse_diagonal(which, level)) < RTOL
+        rng = np.random.Generator(np.random.PCG64(29))
+        u0, rhs = rng.uniform(-1, 1, g.size(capi.OP_STOKES)), rng.uniform(-1, 1, g.size(capi.OP_STOKES))
+        assert relerr(g.rhs_correction(u0, rhs), o.rhs_correction(u0, rhs)) < RTOL
+        xg, rg, rcg = g.solve(allow_failure=True)
+        assert rcg == 0 and rg.final_linear_residual <= rg.solver_tolerance
+        o.opt.n_cheap_steps = 140
+        oo = capi.Solver(oracle_lib, p, n_cheap_steps=140)
+        xo, ro, rco = oo.solve(allow_failure=True)
+        oo.close()
+        hg, ho = np.array(rg.history[:rg.n_history]), np.array(ro.history[:ro.n_history])
+        kg, ko = int(np.argmax(hg <= 2 * rg.solver_tolerance)), int(np.argmax(ho <= 2 * ro.solver_tolerance))
+        assert abs(kg - ko) <= 2, (kg, ko)
+        assert np.allclose(hg[:80], ho[:80], rtol=1e-3)
+    finally:
+        g.close(); o.close()
