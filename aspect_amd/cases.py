@@ -68,6 +68,7 @@ class StokesProblem:
     free_surface: tuple = field(default=None, repr=False)
     hier: bm.BoxHierarchy = field(default=None, repr=False)
     make_hierarchy: callable = None     # (refinement, only_finest) -> hierarchy (other geometries than the box)
+    boundary_velocity: callable = None  # x -> prescribed velocity on the constrained nodes (inhomogeneous Dirichlet)
     pressure_scaling_from_mesh: callable = None   # finest level -> lambda (helper_functions.cc:252-350)
 
     def _hierarchy(self, only_finest):
@@ -90,6 +91,15 @@ class StokesProblem:
         else:
             self.p0 = np.zeros(fin.n_dofs_p)
         self._free_surface_tables(fin)
+        self.u0 = None
+        if self.boundary_velocity is not None:
+            # constraints.distribute(0): the zero vector carrying the boundary values (local_smoothing.cc:775-787)
+            u = np.zeros((fin.n_nodes_v, self.dim))
+            con = fin.cmask_v != 0
+            u[con] = self.boundary_velocity(fin.node_coords_v()[con])
+            bits = ((fin.cmask_v[:, None] >> np.arange(self.dim)[None, :]) & 1).astype(bool)
+            u[~bits] = 0.0
+            self.u0 = np.concatenate([u.reshape(-1), np.zeros(fin.n_dofs_p)])
         return self
 
     def _free_surface_tables(self, fin):
@@ -408,3 +418,55 @@ def nsinker_shell(refinement, n_sinkers=5, ratio=1e2, jump=100.0, averaging="har
         n_cheap=n_cheap, n_expensive=n_expensive,
         make_hierarchy=lambda r, only_finest: sm.ShellHierarchy(r, 0.54, 1.0, zero_velocity=True, only_finest=only_finest),
         pressure_scaling_from_mesh=scaling)
+
+
+def hollow_sphere_solution(x, m=-1):
+    """Analytic velocity [n][3] and pressure [n] of the hollow-sphere benchmark (Thieulot, Solid Earth
+    2017, viscosity parameter m = -1: mu = 1) as benchmarks/hollow_sphere/hollow_sphere.cc:47-128
+    evaluates it: gamma = 1, R1 = 0.5, R2 = 1, g = 1, rho_0 = 1000."""
+    assert m == -1
+    R1, R2, gam = 0.5, 1.0, 1.0
+    r = np.linalg.norm(x, axis=1)
+    theta = np.arccos(np.clip(x[:, 2] / r, -1.0, 1.0))
+    phi = np.arctan2(x[:, 1], x[:, 0])
+    alpha = -gam * (R2 ** 3 - R1 ** 3) / (R2 ** 3 * np.log(R1) - R1 ** 3 * np.log(R2))
+    beta = -3 * gam * (np.log(R2) - np.log(R1)) / (R1 ** 3 * np.log(R2) - R2 ** 3 * np.log(R1))
+    fr = alpha / r ** 2 + beta * r
+    gr = -2.0 / r ** 2 * (alpha * np.log(r) + beta / 3.0 * r ** 3 + gam)
+    vr, vt, vp = gr * np.cos(theta), fr * np.sin(theta), fr * np.sin(theta)
+    st, ct, sp, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
+    v = np.stack([st * cp * vr + ct * cp * vt - sp * vp, st * sp * vr + ct * sp * vt + cp * vp, ct * vr - st * vt], axis=1)
+    p = 2.0 / r * gr * np.cos(theta) + 1000.0 * (R2 - r)
+    return v, p
+
+
+def hollow_sphere(refinement=1, tol=1e-8, n_cheap=200):
+    """tests/hollow_sphere_gmg.prm: shell R in [0.5, 1] on the 12-cell coarse mesh, prescribed
+    (analytic) velocity on both spheres, mu = 1, the benchmark's density (hollow_sphere.cc:352-375,
+    m = -1) under `Material averaging = harmonic average` (density averaged too), radial gravity 1,
+    tolerance 1e-8, 200 cheap steps; first linearisation point = the adiabatic pressure rho_0 g (R2 - r)."""
+    from . import shellmesh as sm
+    R1, R2, gam = 0.5, 1.0, 1.0
+    alpha = -gam * (R2 ** 3 - R1 ** 3) / (R2 ** 3 * np.log(R1) - R1 ** 3 * np.log(R2))
+    beta = -3 * gam * (np.log(R2) - np.log(R1)) / (R1 ** 3 * np.log(R2) - R2 ** 3 * np.log(R1))
+
+    def density(x):
+        r = np.linalg.norm(x, axis=1)
+        ct = x[:, 2] / r
+        return -(alpha / r ** 4 * (8 * np.log(r) - 6) + 8.0 / 3.0 * beta / r + 8 * gam / r ** 4) * ct + 1000.0
+
+    def force_q(level):
+        xq = level.qpoint_coords()
+        flat = xq.reshape(-1, 3)
+        rho = density(flat).reshape(level.n_cells, -1)
+        avg = rho.shape[1] / np.sum(1.0 / rho, axis=1)
+        rhat = flat / np.linalg.norm(flat, axis=1, keepdims=True)
+        return (-np.repeat(avg, rho.shape[1])[:, None] * rhat).reshape(xq.shape)
+
+    return StokesProblem(
+        name=f"hollow_sphere_r{refinement}", dim=3, refinement=refinement, bc=None,
+        eta=lambda x: np.ones(x.shape[0]), force=None, force_q=force_q, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=1.0 / (1e4 / (6336000.0 - 3481000.0) * (R2 - R1)), tol=tol, n_cheap=n_cheap, n_expensive=1000,
+        initial_pressure=lambda x: 1000.0 * (R2 - np.linalg.norm(x, axis=1)),
+        boundary_velocity=lambda x: hollow_sphere_solution(x)[0],
+        make_hierarchy=lambda r, only_finest: sm.ShellHierarchy(r, R1, R2, zero_velocity=True, only_finest=only_finest, n_coarse=12))

@@ -81,8 +81,13 @@ def _coons(corners, s, t):
     return _unit((1 - t_) * bottom + t_ * top + (1 - s_) * left + s_ * right - bil)
 
 
-def coarse_trees(r_inner, r_outer):
-    """96 trees: (corner directions [4][3], r0, r1)."""
+def coarse_trees(r_inner, r_outer, n_coarse=96):
+    """The trees as (corner directions [4][3], r0, r1): 96 (the default hyper_shell of the geometry
+    model) or 12 (`Cells along circumference = 12`: the rhombic dodecahedron itself, one radial layer,
+    tests/hollow_sphere_gmg.prm; its first refinement is the 96-cell mesh)."""
+    if n_coarse == 12:
+        return [(quad, r_inner, r_outer) for quad in rhombic_dodecahedron_faces()]
+    assert n_coarse == 96
     trees = []
     half = np.array([0.0, 0.5, 1.0])
     rm = 0.5 * (r_inner + r_outer)
@@ -200,9 +205,10 @@ class ShellLevel:
 
     def _expected_nodes(self, degree):
         # closed quadrilateral surface mesh: F faces, E = 2F edges, V = F + 2 vertices
-        F = 48 * 4 ** self.level
+        coarse_faces, coarse_layers = (48, 2) if len(self.trees) == 96 else (12, 1)
+        F = coarse_faces * 4 ** self.level
         V, E = F + 2, 2 * F
-        layers = 2 * (1 << self.level)
+        layers = coarse_layers * (1 << self.level)
         if degree == 1:
             return V * (layers + 1)
         return (V + E + F) * (2 * layers + 1)
@@ -239,6 +245,47 @@ class ShellLevel:
             self.inv_jacobian[a:a + len(cells)] = np.linalg.inv(J)
             self.jxw[a:a + len(cells)] = det * W[None, :]
             self._xq[a:a + len(cells)] = np.einsum("qk,ckd->cqd", Nq, X)
+
+    def mapped_quadrature(self, x1d, w1d):
+        """Physical positions [cell][q][3] and JxW [cell][q] of the tensor quadrature (x1d, w1d) per
+        direction (q lexicographic, x fastest) under the degree-4 mapping: what FEValues gives the
+        error postprocessors."""
+        nq1 = len(x1d)
+        V5, D5 = _lagrange(_GLL5, np.asarray(x1d))
+        sup = np.indices((5,) * 3).reshape(3, -1)[::-1].T
+        xi = _GLL5[sup]
+        q = np.indices((nq1,) * 3).reshape(3, -1)[::-1].T
+        nq = q.shape[0]
+        G = np.empty((3, nq, 125))
+        Nq = np.ones((nq, 125))
+        for e in range(3):
+            g = np.ones((nq, 125))
+            for d in range(3):
+                g *= (D5 if d == e else V5)[q[:, d]][:, sup[:, d]]
+            G[e] = g
+            Nq *= V5[q[:, e]][:, sup[:, e]]
+        W = np.asarray(w1d)[q[:, 0]] * np.asarray(w1d)[q[:, 1]] * np.asarray(w1d)[q[:, 2]]
+        X = self.map_points(np.arange(self.n_cells), xi)
+        J = np.einsum("eqk,ckd->cqde", G, X)
+        return np.einsum("qk,ckd->cqd", Nq, X), np.linalg.det(J) * W[None, :]
+
+    def mapped_face_quadrature(self, cells, x1d, w1d, top=True):
+        """Positions [face][q][3] and JxW [face][q] on the radial faces (xi_2 = 1 or 0) of `cells`."""
+        nq1 = len(x1d)
+        V5, D5 = _lagrange(_GLL5, np.asarray(x1d))
+        Vz, _ = _lagrange(_GLL5, np.array([1.0 if top else 0.0]))
+        sup = np.indices((5,) * 3).reshape(3, -1)[::-1].T
+        xi = _GLL5[sup]
+        q = np.indices((nq1,) * 2).reshape(2, -1)[::-1].T
+        nq = q.shape[0]
+        N = V5[q[:, 0]][:, sup[:, 0]] * V5[q[:, 1]][:, sup[:, 1]] * Vz[0][sup[:, 2]][None, :]
+        T0 = D5[q[:, 0]][:, sup[:, 0]] * V5[q[:, 1]][:, sup[:, 1]] * Vz[0][sup[:, 2]][None, :]
+        T1 = V5[q[:, 0]][:, sup[:, 0]] * D5[q[:, 1]][:, sup[:, 1]] * Vz[0][sup[:, 2]][None, :]
+        X = self.map_points(np.asarray(cells, dtype=np.int64), xi)
+        t0, t1 = np.einsum("qk,ckd->cqd", T0, X), np.einsum("qk,ckd->cqd", T1, X)
+        area = np.linalg.norm(np.cross(t0, t1), axis=-1)
+        W = np.asarray(w1d)[q[:, 0]] * np.asarray(w1d)[q[:, 1]]
+        return np.einsum("qk,ckd->cqd", N, X), area * W[None, :]
 
     # -- the rest of boxmesh.Level's interface -------------------------------
     def node_coords_v(self):
@@ -291,8 +338,8 @@ class ShellHierarchy:
 
     dim = 3
 
-    def __init__(self, refinement, r_inner=0.54, r_outer=1.0, zero_velocity=True, only_finest=False):
-        trees = coarse_trees(r_inner, r_outer)
+    def __init__(self, refinement, r_inner=0.54, r_outer=1.0, zero_velocity=True, only_finest=False, n_coarse=96):
+        trees = coarse_trees(r_inner, r_outer, n_coarse)
         first = refinement if only_finest else 0
         self.levels = [ShellLevel(trees, l, r_inner, r_outer, zero_velocity) for l in range(first, refinement + 1)]
         self.bc = "zero velocity on both spheres" if zero_velocity else "none"

@@ -58,7 +58,7 @@ def parse(path):
         m = re.search(r"RMS, max velocity:\s+(\S+) m/s, (\S+) m/s", line)
         if m:
             out.setdefault("rms_max_velocity", []).append([float(m.group(1)), float(m.group(2))])
-        m = re.search(r"Errors u_L1, p_L1, u_L2, p_L2:?\s+(\S+),\s*(\S+),\s*(\S+),\s*(\S+)", line)
+        m = re.search(r"Errors u_L1, p_L1, u_L2, p_L2(?: topo_L2)?:?\s+([^,\s]+),\s*([^,\s]+),\s*([^,\s]+),\s*([^,\s]+)", line)
         if m:
             out["errors_uL1_pL1_uL2_pL2"] = [float(m.group(i)) for i in range(1, 5)]
     return out

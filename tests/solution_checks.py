@@ -87,3 +87,37 @@ def relative_residual_second_iteration(solver, p, x1, rep1):
     x2, rep2, rc = solver.solve(rhs=rhs, x0=x1)
     r0 = rep1.solver_tolerance / p.tol
     return rep2.initial_nonlinear_residual / r0, rep2
+
+
+def hollow_sphere_errors(p, x):
+    """u_L1, p_L1, u_L2, p_L2 of benchmarks/hollow_sphere/hollow_sphere.cc:513-556 (QGauss(4) per
+    direction under the degree-4 mapping, cell-wise errors stored as float) and the relative residual
+    bookkeeping needs: x is the solve's solution (constrained entries zero); the finite element
+    velocity is x + u0 (the prescribed boundary values), the pressure lambda * p_hat shifted so that
+    its mean over the outer sphere is 0 (Pressure normalization = surface)."""
+    from aspect_amd import cases
+    fin = p.hier.finest
+    nu = fin.n_dofs_v
+    u = (x[:nu] + p.u0[:nu]).reshape(-1, 3)
+    pr = p.pressure_scaling * x[nu:]
+    gx, gw = _gauss(4)
+    N2, N1 = bm.q2_shape(gx), bm.q1_shape(gx)
+    S2, S1 = bm.tensor_shape([N2] * 3), bm.tensor_shape([N1] * 3)           # [64][27], [64][8]
+    # surface normalisation: mean of p over the outer sphere
+    cells, _ = fin.boundary_faces(1)
+    xf, wf = fin.mapped_face_quadrature(cells, gx, gw, top=True)
+    F1 = np.kron(N1, N1)                                                     # [16][4] on the face xi_2 = 1
+    top_nodes = fin.cell_nodes_p[cells.astype(np.int64)][:, 4:8].astype(np.int64)
+    pf = np.einsum("qa,fa->fq", F1, pr[top_nodes])
+    pr = pr - (pf * wf).sum() / wf.sum()
+    xq, jxw = fin.mapped_quadrature(gx, gw)
+    uq = np.einsum("qi,cid->cqd", S2, u[fin.cell_nodes_v.astype(np.int64)])
+    pq = np.einsum("qi,ci->cq", S1, pr[fin.cell_nodes_p.astype(np.int64)])
+    ua, pa = cases.hollow_sphere_solution(xq.reshape(-1, 3))
+    du, dp = uq - ua.reshape(uq.shape), pq - pa.reshape(pq.shape)
+    f32, f64 = np.float32, np.float64
+    e_u1 = (np.abs(du).sum(axis=2) * jxw).sum(axis=1).astype(f32).astype(f64)
+    e_p1 = (np.abs(dp) * jxw).sum(axis=1).astype(f32).astype(f64)
+    e_u2 = np.sqrt(((du ** 2).sum(axis=2) * jxw).sum(axis=1)).astype(f32).astype(f64)
+    e_p2 = np.sqrt((dp ** 2 * jxw).sum(axis=1)).astype(f32).astype(f64)
+    return e_u1.sum(), e_p1.sum(), np.sqrt((e_u2 ** 2).sum()), np.sqrt((e_p2 ** 2).sum())

@@ -734,3 +734,10 @@ def test_config4_nsinker_spherical_shell(hip_lib, oracle_lib):
         assert np.allclose(hg[:80], ho[:80], rtol=1e-3)
     finally:
         g.close(); o.close()
+
+
+def test_hollow_sphere_golden_on_the_gpu(hip_lib):
+    """tests/hollow_sphere_gmg through the HIP library: agmg_rhs_correction for the prescribed boundary
+    velocities, 33+0 iterations, the reference's relative residuals and analytic error norms."""
+    from test_oracle_goldens import _solve_hollow_sphere, check_hollow_sphere
+    check_hollow_sphere(*_solve_hollow_sphere(lambda p: capi.Solver(hip_lib, p)))
