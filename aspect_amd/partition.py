@@ -24,7 +24,8 @@ import numpy as np
 
 def cell_ranks(glev, size):
     """Owner rank of every cell of a global level (contiguous runs of coarse cells)."""
-    n_coarse = int(np.prod(glev.reps))
+    # trees of the forest: the coarse cells of a box (reps), or of another geometry (n_trees: the shell's 96)
+    n_coarse = int(getattr(glev, "n_trees", 0)) or int(np.prod(glev.reps))
     if n_coarse % size:
         raise ValueError(f"{n_coarse} coarse cells do not split over {size} ranks")
     per_coarse = glev.n_cells // n_coarse

@@ -318,6 +318,10 @@ class ShellLevel:
         return cells, np.full(cells.size, fno, dtype=np.uint8)
 
     @property
+    def n_trees(self):
+        return len(self.trees)
+
+    @property
     def n_dofs_v(self):
         return 3 * self.n_nodes_v
 

@@ -5,7 +5,7 @@ Every rank owns one subdomain of the same global problem, runs the HIP library o
 with the ghost exchange / all-reduce going through aspect_amd.parallel.Transport, and compares the
 OWNED entries of every result with the serial CPU oracle applied to the GLOBAL problem.
 
-usage: dist_worker.py <case> <backend: gloo|nccl|gloo-dev> [what: all|vmult]
+usage: dist_worker.py <case> <backend: gloo|nccl|gloo-dev> [what: all|ops|vmult]
 All ranks may share one GPU (gloo: the library stages messages through host memory; gloo-dev: the
 library hands out device pointers as it does for RCCL and the transport stages them itself)."""
 import os
@@ -45,6 +45,8 @@ def global_problem(case, world):
         reps = {1: [1, 1], 2: [2, 1], 4: [2, 2]}[world]
     elif case == "deformed":
         p = cases.deformed_sinker_box(3, 2)
+    elif case == "shell":         # BASELINE configs[3]: 96 trees of the spherical shell over the ranks
+        return cases.nsinker_shell(1, n_cheap=40).build()
     else:
         raise ValueError(case)
     p.reps = reps
@@ -95,7 +97,7 @@ def main():
     lo, go = loc.owned_block()
     check("Stokes", relerr(hip.vmult(capi.OP_STOKES, loc.to_local(x))[lo], ora.vmult(capi.OP_STOKES, x)[go]), RTOL)
     check("BT", relerr(hip.vmult(capi.OP_BT, loc.to_local(x))[lo], ora.vmult(capi.OP_BT, x)[go]), RTOL)
-    if what == "all":
+    if what in ("all", "ops"):
         # transfer
         for level in range(1, nl):
             for which in (capi.OP_A, capi.OP_MASS):
@@ -136,6 +138,11 @@ def main():
             a = hip.vcycle(which, fin.to_local_v(src) if vel else fin.to_local_p(src))
             check(f"vcycle {which}", relerr(a[lo_], ora.vcycle(which, src)[go_]), 1e-9)
         check("precondition", relerr(hip.precondition(loc.to_local(x))[lo], ora.precondition(x)[go]), 1e-9)
+    if what == "ops" and ranks.rank == 0:
+        print(f"[dist] {case} world={ranks.world} backend={backend}: operators, transfers, V-cycles, preconditioner "
+              f"(exchanges {tr.n_exchange}, all-reduces {tr.n_allreduce})", flush=True)
+    if what == "all":
+        fin = loc.hier.finest
         # the whole solve
         xg, rg, _ = hip.solve()
         xo, ro, _ = ora.solve()

@@ -64,10 +64,15 @@ def test_world_size_2_gloo_partition_and_transport():
                                              (2, "deformed", "gloo"), (4, "box2d", "gloo"),
                                              (2, "nsinker_idr", "gloo"), (4, "nsinker_idr", "gloo-dev"),
                                              (2, "free_surface", "gloo"), (8, "free_surface", "gloo-dev"),
+                                             # configs[3]: the shell's 96 trees over 8 ranks (12 each) and over 2
+                                             (8, "shell", "gloo"), (2, "shell", "gloo-dev"),
                                              # device-pointer protocol of the communicator (what RCCL uses)
                                              (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
 def test_distributed_hip_matches_serial_oracle(nproc, case, wire):
-    out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, wire, "all"], 29550 + nproc)
+    # (the shell's solve creeps to its tolerance for hundreds of iterations, tests/test_oracle_goldens.py:
+    # there everything up to the preconditioner is compared)
+    what = "ops" if case == "shell" else "all"
+    out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, wire, what], 29550 + nproc)
     assert "[dist]" in out
 
 
