@@ -95,7 +95,7 @@ SYMBOLS = [
     "set_free_surface_faces",
     "compute_diagonals", "rhs_correction", "vmult", "vmult_device", "vmult_device_noalloc", "get_inverse_diagonal", "prolongate_add",
     "restrict_add", "setup_smoothers", "get_eigenvalue_estimates", "vcycle", "precondition",
-    "solve", "bench_vmult", "execute_solver_timings", "get_level_kernel_path", "get_cell_data_memory_consumption",
+    "solve", "bench_vmult", "execute_solver_timings", "get_level_kernel_path", "get_overlap_statistics", "get_cell_data_memory_consumption",
     "get_mg_transfer_memory_consumption", "get_constraint_memory_consumption",
     "get_dof_handler_memory_consumption",
 ]
@@ -159,6 +159,7 @@ class Library:
         self.solve = fn("solve", C.c_int, [vp, c_dp, c_dp, C.c_int, C.POINTER(SolveReport)])
         self.bench_vmult = fn("bench_vmult", C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp])
         self.execute_solver_timings = fn("execute_solver_timings", C.c_int, [vp, C.c_int, c_dp])
+        self.get_overlap_statistics = fn("get_overlap_statistics", C.c_int, [vp, C.c_int, c_i32p, c_i32p, c_i32p])
         self.get_level_kernel_path = fn("get_level_kernel_path", C.c_int, [vp, C.c_int, c_i32p, c_i32p, c_i32p])
         for g in ("cell_data", "mg_transfer", "constraint", "dof_handler"):
             setattr(self, f"get_{g}_memory_consumption",
@@ -420,6 +421,12 @@ class Solver:
         self._check(self.lib.execute_solver_timings(self.ctx, n_repeat, out))
         names = ("stokes_vmult", "stokes_preconditioner", "A_preconditioner", "S_preconditioner", "A_block_vmult", "smoother_setup")
         return dict(zip(names, list(out)))
+
+    def overlap_statistics(self, level):
+        """(interior blocks, interface blocks, overlapped operator applications so far)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.get_overlap_statistics(self.ctx, level, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def kernel_path(self, level=ACTIVE):
         """(bricks, layers per brick, blocks) of the kernels that apply the velocity rows of a level."""

@@ -176,6 +176,33 @@ struct agmg_ctx {
   int add_update(std::vector<Msg> &msgs, const Exchange &x, double *vec, int nc);
   // ghost partial sums (x.ghostbuf) -> owners (x.expbuf)
   void add_compress(std::vector<Msg> &msgs, const Exchange &x, int nc);
+  // ---- overlap of the ghost import with the interior blocks: the import runs on a second stream
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_src_ready = nullptr, ev_import_done = nullptr;
+  bool use_overlap = true;    // AGMG_NO_OVERLAP=1: import, then all blocks (the order of round 1)
+  int n_overlapped = 0;       // operator applications that took the overlapped path (tests)
+  bool can_overlap(const DeviceLevel &lv, const EpiArgs &e, const CoeffData &cd, int which) const {
+    return use_overlap && use_blocks && lv.bt.built && lv.bt.blk_order && lv.bt.n_interior > 0 && cstream &&
+           (e.epi == EPI_STORE || e.epi == EPI_RESID || e.epi == EPI_CHEB) &&
+           !((cd.newton || cd.dilation) && which == AGMG_OP_STOKES);
+  }
+  // run `import` (the ghost update of the source vector) on the communication stream, behind everything
+  // already enqueued on the main stream; returns with the main stream free to run the interior blocks
+  int begin_import(const std::function<int()> &import) {
+    AGMG_HIP_CHECK(hipEventRecord(ev_src_ready, stream));
+    AGMG_HIP_CHECK(hipStreamWaitEvent(cstream, ev_src_ready, 0));
+    std::swap(stream, cstream);
+    const int rc = import();
+    std::swap(stream, cstream);
+    if (rc) return rc;
+    AGMG_HIP_CHECK(hipEventRecord(ev_import_done, cstream));
+    return 0;
+  }
+  int end_import() {
+    AGMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_import_done, 0));
+    ++n_overlapped;
+    return 0;
+  }
   int update_ghosts(const Exchange &x, const double *vec) {
     if (!x.active()) return 0;
     std::vector<Msg> m;
@@ -331,7 +358,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.prol_parent_v); dfree(l.prol_pos_v); dfree(l.prol_parent_p); dfree(l.prol_pos_p);
   dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
   dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8); dfree(l.bt.lidT);
-  dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list);
+  dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list); dfree(l.bt.blk_order);
   dfree(l.bk.gnode); dfree(l.bk.bcell); dfree(l.bk.pidx); dfree(l.bk.fx_nodes); dfree(l.bk.fx_ptr); dfree(l.bk.fx_list);
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.gid_v); dfree(l.gid_p);
@@ -440,6 +467,18 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
     }
   std::vector<uint32_t> fill(sh_ptr.begin(), sh_ptr.end() - 1);
   for (auto &pr : sh_pairs) sh_list[fill[sh_index[pr.first]]++] = pr.second;
+  if (lv.n_owned_v < nn) {   // distributed level: interior blocks (no ghost node) first, then interface blocks
+    std::vector<uint32_t> order, iface;
+    for (int b = 0; b < nb; ++b) {
+      bool ghost = false;
+      const int U = (int)blk_hdr[(size_t)b * 4];
+      for (int l = 0; l < U && !ghost; ++l) ghost = (int)(unodes[(size_t)b * max_u + l] & NODE_MASK) >= lv.n_owned_v;
+      (ghost ? iface : order).push_back((uint32_t)b);
+    }
+    bt.n_interior = (int)order.size();
+    order.insert(order.end(), iface.begin(), iface.end());
+    CHECK(upload(&bt.blk_order, order));
+  }
   bt.block_cells = bc; bt.n_blocks = nb; bt.max_unodes = max_u;
   bt.n_shared = (int)sh_nodes.size(); bt.n_shared_slots = nslots;
   CHECK(upload(&bt.blk_hdr, blk_hdr));
@@ -845,8 +884,15 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
   }
   // distributed: src.update_ghost_values(); cell loop; dst.compress(add); epilogue on the owned rows
   if (which == 0) {
-    CHECK(update_ghosts(lv.xv, x));
-    CHECK(launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_GHOST));
+    if (can_overlap(lv, e, cd, AGMG_OP_A)) {
+      CHECK(begin_import([&] { return update_ghosts(lv.xv, x); }));
+      CHECK(launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_INTERIOR));
+      CHECK(end_import());
+      CHECK(launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_INTERFACE));
+    } else {
+      CHECK(update_ghosts(lv.xv, x));
+      CHECK(launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_GHOST));
+    }
     CHECK(compress(lv.xv));
     return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_OWNED);
   }
@@ -863,8 +909,15 @@ int agmg_ctx::bt_residual(double *dst, const double *b, const double *p) {
   EpiArgs e;
   e.epi = b ? EPI_RESID : EPI_STORE; e.dst = dst; e.b = b; e.x = nullptr;
   if (!dist()) return op_velocity(lv, active_coeff(), AGMG_OP_BT, nullptr, p, e);
-  CHECK(update_ghosts(lv.xp, p));
-  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_GHOST));
+  if (can_overlap(lv, e, active_coeff(), AGMG_OP_BT)) {
+    CHECK(begin_import([&] { return update_ghosts(lv.xp, p); }));
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_INTERIOR));
+    CHECK(end_import());
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_INTERFACE));
+  } else {
+    CHECK(update_ghosts(lv.xp, p));
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_GHOST));
+  }
   CHECK(compress(lv.xv));
   return launch_op(stream, lv, active_coeff(), AGMG_OP_BT, nullptr, p, slots_u, nullptr, e, use_blocks, PH_OWNED);
 }
@@ -902,10 +955,20 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
     return launch_face_term(stream, lv.dim, faces, lv.cmask_v, src, dst, eu_in.epi == EPI_RESID ? -1.0 : 1.0);
   }
   std::vector<Msg> m;
-  CHECK(add_update(m, lv.xv, const_cast<double *>(src), lv.xv.nc));
-  CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
-  CHECK(exchange(m));
-  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_GHOST));
+  auto import = [&]() -> int {
+    CHECK(add_update(m, lv.xv, const_cast<double *>(src), lv.xv.nc));
+    CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
+    return exchange(m);
+  };
+  if (can_overlap(lv, eu, active_coeff(), AGMG_OP_STOKES)) {
+    CHECK(begin_import(import));
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_INTERIOR));
+    CHECK(end_import());
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_INTERFACE));
+  } else {
+    CHECK(import());
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_GHOST));
+  }
   CHECK(launch_pull_p(stream, lv, slots_p, 1, ep, PH_GHOST));
   m.clear();
   add_compress(m, lv.xv, lv.xv.nc);
@@ -1873,6 +1936,12 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   c->H.resize(opt->n_levels);
   for (int w = 0; w < 2; ++w) c->send_nodes_h[w].resize(opt->n_levels);
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+  if (const char *e = getenv("AGMG_NO_OVERLAP")) c->use_overlap = atoi(e) == 0;
+  if (opt->world_size > 1 &&
+      (hipStreamCreate(&c->cstream) != hipSuccess || hipEventCreateWithFlags(&c->ev_src_ready, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&c->ev_import_done, hipEventDisableTiming) != hipSuccess)) {
+    set_error("creating the communication stream failed"); delete c; return nullptr;
+  }
   return c;
 }
 
@@ -1916,6 +1985,9 @@ void agmg_destroy(agmg_ctx *c) {
   if (c->dot_out_h) (void)hipHostFree(c->dot_out_h);
   if (c->stage_h) (void)hipHostFree(c->stage_h);
   rccl_comm_destroy(c->rccl_state);
+  if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
+  if (c->ev_src_ready) (void)hipEventDestroy(c->ev_src_ready);
+  if (c->ev_import_done) (void)hipEventDestroy(c->ev_import_done);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2764,6 +2836,17 @@ int agmg_get_level_kernel_path(const agmg_ctx *c, int level, int32_t *n_bricks, 
   if (n_bricks) *n_bricks = bricks ? lv.bk.n_bricks : 0;
   if (layers_per_brick) *layers_per_brick = bricks ? lv.bk.Z : 0;
   if (n_blocks) *n_blocks = (c->use_blocks && lv.bt.built) ? lv.bt.n_blocks : 0;
+  return 0;
+}
+
+int agmg_get_overlap_statistics(const agmg_ctx *c, int level, int32_t *n_interior_blocks, int32_t *n_interface_blocks,
+                                int32_t *n_overlapped_applications) {
+  if (!c || level < 0 || level >= (int)c->L.size()) { set_error("bad level"); return -1; }
+  const BlockTables &bt = c->L[level].bt;
+  const bool split = bt.built && bt.blk_order;
+  if (n_interior_blocks) *n_interior_blocks = split ? bt.n_interior : 0;
+  if (n_interface_blocks) *n_interface_blocks = split ? bt.n_blocks - bt.n_interior : 0;
+  if (n_overlapped_applications) *n_overlapped_applications = c->n_overlapped;
   return 0;
 }
 

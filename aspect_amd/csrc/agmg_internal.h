@@ -90,6 +90,11 @@ struct BlockTables {
   uint32_t *sh_list = nullptr;    // slot positions, in block order; positions >= n_shared_slots address
                                   // the receive buffer of the ghost exchange (remote partial sums)
   int n_shared_owned = 0;         // shared nodes [0, n_shared_owned) are owned, the rest ghosts
+  // distributed levels: blocks without a ghost node ("interior") first, then the blocks that read
+  // ghost values ("interface"): the interior ones run while the ghost import is in flight
+  // (deal.II's cell_loop overlaps the same way, matrix_free_operators.cc:357, 794)
+  uint32_t *blk_order = nullptr;  // [n_blocks]
+  int n_interior = 0;
   size_t bytes = 0;
 };
 
@@ -198,7 +203,10 @@ int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
 // phase (distributed levels): PH_ALL everything at once (one rank); PH_GHOST the part before the
 // ghost exchange (cell phase + partial sums of ghost nodes into Exchange::ghostbuf); PH_OWNED the
 // part after it (sums of owned nodes including the received remote partial sums + epilogue)
-enum Phase { PH_ALL = 0, PH_GHOST = 1, PH_OWNED = 2 };
+// overlapped form of PH_GHOST: PH_INTERIOR = the cell phase of the blocks that read no ghost value
+// (may run before the ghost import has landed), PH_INTERFACE = the remaining blocks + the partial sums
+// of the ghost nodes
+enum Phase { PH_ALL = 0, PH_GHOST = 1, PH_OWNED = 2, PH_INTERIOR = 3, PH_INTERFACE = 4 };
 int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e, int phase = PH_ALL);
 // Whole velocity-row application: cell phase + reduction + epilogue `eu` on the velocity rows.
 // Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.

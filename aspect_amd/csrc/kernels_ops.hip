@@ -459,6 +459,8 @@ struct BlkArgs {
   const uint4 *uent8;        // [n_blocks][max_u]: 8 LDS slot indices (16 bit each) per local node
   const uint16_t *lidT;      // [cstride][LID_ROW]: local id (within its block) of each cell node
   double *slots_sh;
+  const uint32_t *blk_list;  // != nullptr: the launch covers blocks blk_list[blk_first + 0 .. gridDim.x)
+  int blk_first;
 };
 
 // LDS carve-up of k_cells_blk (bytes); max_u = largest number of unique nodes of any block
@@ -567,7 +569,8 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
 #if AGMG_ABLATE & 256
   const int blk = blockIdx.x;
 #else
-  const int blk = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  const int item = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  const int blk = B.blk_list ? (int)B.blk_list[B.blk_first + item] : item;
 #endif
   const int c0 = blk * BC;
   const int cell_l = c0 + wave * CPW + j;
@@ -1131,6 +1134,9 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
   // once per outer Krylov iteration)
   if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB) ||
       ((cd.newton || cd.dilation) && which == AGMG_OP_STOKES)) {
+    // the slot path has no interior / interface split: everything waits for the ghost import
+    if (phase == PH_INTERIOR) return 0;
+    if (phase == PH_INTERFACE) phase = PH_GHOST;
     if (phase != PH_OWNED) {
       const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
       if (rc) return rc;
@@ -1160,17 +1166,28 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
 #if AGMG_ABLATE & 1024
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)4000000 * 8 * 8);
 #endif
-  BlkArgs b{dbg_buf, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), bt.lidT, slots_u};
+  BlkArgs b{dbg_buf, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), bt.lidT, slots_u,
+            nullptr, 0};
+  int n_launch = bt.n_blocks;
+  if (phase == PH_INTERIOR || phase == PH_INTERFACE) {
+    if (!bt.blk_order) { set_error("launch_op: level has no interior / interface block lists"); return -1; }
+    b.blk_list = bt.blk_order;
+    b.blk_first = phase == PH_INTERIOR ? 0 : bt.n_interior;
+    n_launch = phase == PH_INTERIOR ? bt.n_interior : bt.n_blocks - bt.n_interior;
+  }
   const bool perq = cd.nqv > 1;
   const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;
   const int lds = bt.max_unodes;
   const bool gen = L.geom == AGMG_GEOM_GENERAL;
-  int rc;
-  if (L.dim == 3) rc = gen ? launch_blk_op<3, true>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq)
-                           : launch_blk_op<3, false>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq);
-  else rc = gen ? launch_blk_op<2, true>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq)
-                : launch_blk_op<2, false>(s, a, b, eu, bt.n_blocks, lds, which, comp, perq);
+  int rc = 0;
+  if (n_launch > 0) {
+    if (L.dim == 3) rc = gen ? launch_blk_op<3, true>(s, a, b, eu, n_launch, lds, which, comp, perq)
+                             : launch_blk_op<3, false>(s, a, b, eu, n_launch, lds, which, comp, perq);
+    else rc = gen ? launch_blk_op<2, true>(s, a, b, eu, n_launch, lds, which, comp, perq)
+                  : launch_blk_op<2, false>(s, a, b, eu, n_launch, lds, which, comp, perq);
+  }
   if (rc) return rc;
+  if (phase == PH_INTERIOR) { AGMG_HIP_CHECK(hipGetLastError()); return 0; }
   AGMG_HIP_CHECK(hipGetLastError());
 #if AGMG_ABLATE & 1024
   {
@@ -1191,7 +1208,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
             d[0] / nw, p1 / nw, p2 / nw, p3 / nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw);
   }
 #endif
-  if (phase == PH_GHOST) return fix(bt.n_shared_owned, bt.n_shared - bt.n_shared_owned, true);
+  if (phase == PH_GHOST || phase == PH_INTERFACE) return fix(bt.n_shared_owned, bt.n_shared - bt.n_shared_owned, true);
   if (!ep) return fix(0, bt.n_shared, false);
   if (bt.n_shared <= 0) return launch_pull_p(s, L, slots_p, 1, *ep, PH_ALL);
   {  // one launch for the velocity fix-up and the pressure pull

@@ -340,6 +340,13 @@ int agmg_execute_solver_timings(agmg_ctx *ctx, int n_repeat, double seconds[6]);
  * slot path. */
 int agmg_get_level_kernel_path(const agmg_ctx *ctx, int level, int32_t *n_bricks, int32_t *layers_per_brick, int32_t *n_blocks);
 
+/* Distributed contexts: how a level's blocks split into interior blocks (no ghost node: they run
+ * while the ghost import of the source vector is in flight, as deal.II's cell_loop overlaps the
+ * import with its interior cell batches, matrix_free_operators.cc:357, 794) and interface blocks,
+ * and how many operator applications of the context have taken the overlapped path so far. */
+int agmg_get_overlap_statistics(const agmg_ctx *ctx, int level, int32_t *n_interior_blocks, int32_t *n_interface_blocks,
+                                int32_t *n_overlapped_applications);
+
 /* memory getters (stokes_matrix_free.h:75-98; postprocess/memory_statistics.cc:44-59) */
 size_t agmg_get_cell_data_memory_consumption(const agmg_ctx *ctx);
 size_t agmg_get_mg_transfer_memory_consumption(const agmg_ctx *ctx);

@@ -24,7 +24,7 @@ def load():
         if not os.path.exists(path):
             build()
         _LIB = capi.Library(path, "oracle_",
-                            optional=("vmult_device", "vmult_device_noalloc", "get_level_kernel_path", "execute_solver_timings", "bench_vmult", "set_communicator", "rccl_get_unique_id", "set_communicator_rccl",
+                            optional=("vmult_device", "vmult_device_noalloc", "get_level_kernel_path", "get_overlap_statistics", "execute_solver_timings", "bench_vmult", "set_communicator", "rccl_get_unique_id", "set_communicator_rccl",
                                       "get_cell_data_memory_consumption",
                                       "get_mg_transfer_memory_consumption",
                                       "get_constraint_memory_consumption",

@@ -45,6 +45,10 @@ def global_problem(case, world):
         reps = {1: [1, 1], 2: [2, 1], 4: [2, 2]}[world]
     elif case == "deformed":
         p = cases.deformed_sinker_box(3, 2)
+    elif case == "nsinker_r3":    # several blocks per rank: interior blocks overlap the ghost import
+        p = cases.nsinker_box(3, n_sinkers=4, ratio=1e4)
+    elif case == "box3d_r3":
+        p = cases.convection_box(3, 3)
     elif case == "shell":         # BASELINE configs[3]: 96 trees of the spherical shell over the ranks
         return cases.nsinker_shell(1, n_cheap=40).build()
     else:
@@ -160,6 +164,17 @@ def main():
         if ranks.rank == 0:
             print(f"[dist] {case} world={ranks.world} backend={backend}: iterations {rg.n_cheap_iterations} "
                   f"(oracle {ro.n_cheap_iterations}), exchanges {tr.n_exchange}, all-reduces {tr.n_allreduce}", flush=True)
+    if case in ("nsinker_r3", "box3d_r3"):
+        # deal.II's cell_loop overlaps the ghost import with the interior cells; here: interior blocks
+        # (a rank that owns every node it touches -- rank 0 -- imports nothing and has no split)
+        n_int, n_ifc, n_over = (int(ranks.max_over_ranks(float(v))) for v in hip.overlap_statistics(nl - 1))
+        want = os.environ.get("AGMG_NO_OVERLAP", "0") == "0"
+        if want and not (n_int > 0 and n_ifc > 0 and n_over > 0):
+            fails.append(f"no overlapped operator application: interior {n_int}, interface {n_ifc}, overlapped {n_over}")
+        if not want and n_over != 0:
+            fails.append("overlap although AGMG_NO_OVERLAP=1")
+        if ranks.rank == 0:
+            print(f"[dist] finest level: {n_int} interior + {n_ifc} interface blocks, {n_over} overlapped operator applications", flush=True)
     nfail = ranks.sum_over_ranks(float(len(fails)))
     for f in fails:
         print(f"[dist rank {ranks.rank}] FAIL {f}", flush=True)

@@ -66,6 +66,8 @@ def test_world_size_2_gloo_partition_and_transport():
                                              (2, "free_surface", "gloo"), (8, "free_surface", "gloo-dev"),
                                              # configs[3]: the shell's 96 trees over 8 ranks (12 each) and over 2
                                              (8, "shell", "gloo"), (2, "shell", "gloo-dev"),
+                                             # several blocks per rank: the interior ones run under the ghost import
+                                             (2, "nsinker_r3", "gloo"), (2, "nsinker_r3", "gloo-dev"), (4, "box3d_r3", "gloo-dev"),
                                              # device-pointer protocol of the communicator (what RCCL uses)
                                              (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
 def test_distributed_hip_matches_serial_oracle(nproc, case, wire):
@@ -82,3 +84,11 @@ def test_transport_device_callbacks_on_a_one_rank_rccl_group():
     "nccl" group; the all-reduce callback gets a raw device pointer and the library-stream handle."""
     out = _launch(1, [os.path.join("tests", "dist_nccl1_worker.py")], 29549)
     assert "[nccl1] ok" in out
+
+
+@pytest.mark.gpu
+def test_distributed_without_overlap_gives_the_same_result(monkeypatch):
+    """AGMG_NO_OVERLAP=1: ghost import first, then every block (the order of round 1)."""
+    monkeypatch.setenv("AGMG_NO_OVERLAP", "1")
+    out = _launch(2, [os.path.join("tests", "dist_worker.py"), "nsinker_r3", "gloo-dev", "all"], 29571)
+    assert "[dist]" in out and "0 overlapped" in out
