@@ -50,15 +50,21 @@ __device__ __forceinline__ void interp3T(double &a, double &b, double &c) {
 }
 // collocation derivative at the (equispaced) Gauss points, times the spacing
 __device__ __forceinline__ void deriv3(double a, double b, double c, double &d0, double &d1, double &d2_) {
-  d0 = fma(-1.5, a, fma(2.0, b, -0.5 * c));
-  d1 = 0.5 * (c - a);
-  d2_ = fma(0.5, a, fma(-2.0, b, 1.5 * c));
+  // centred difference h and second difference s: d0 = h - s, d2 = h + s (6 operations instead of 8)
+  const double h = 0.5 * (c - a);
+  const double s = fma(-2.0, b, a + c);
+  d0 = h - s;
+  d1 = h;
+  d2_ = h + s;
 }
 // transpose of deriv3, accumulating
 __device__ __forceinline__ void deriv3T(double f0, double f1, double f2, double &ga, double &gb, double &gc) {
-  ga += fma(-1.5, f0, 0.5 * (f2 - f1));
-  gb += 2.0 * (f0 - f2);
-  gc += fma(1.5, f2, 0.5 * (f1 - f0));
+  // with t = f0 - f2 and m = (f0 + f1 + f2) / 2: rows (-t - m, 2 t, -t + m) (8 operations instead of 10)
+  const double t = f0 - f2;
+  const double m = 0.5 * ((f0 + f1) + f2);
+  ga -= t + m;
+  gb = fma(2.0, t, gb);
+  gc += m - t;
 }
 __host__ __device__ constexpr double dcol(int q, int i) {  // collocation derivative matrix * spacing
   return q == 0 ? (i == 0 ? -1.5 : (i == 1 ? 2.0 : -0.5))
@@ -207,6 +213,23 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
     compc[d] = (d == c) ? (2.0 / 3.0) * cw[d] : 0.0;
   }
   (void)lamc; (void)ptc; (void)compc;
+  // Cartesian, incompressible, no Newton terms: the gradient rows stay in reference space (no 1/h scaling of
+  // the 9 derivatives of a line); the stress coefficients carry the geometry instead:
+  //   flux_dd = f (cw_dd / h_dd) dref u_c/d xi_dd + f (cw_dd / h_c) dref u_dd/d xi_c
+  constexpr bool FOLD = !GEN && !COMP && !NEWTON && HAS_U;
+  double Pc[DIM], Qc[DIM], ptcF[DIM];
+  {
+    double ihc = ih[0];
+#pragma unroll
+    for (int d = 1; d < DIM; ++d) ihc = (d == c) ? ih[d] : ihc;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      Pc[d] = cw[d] * ih[d];
+      Qc[d] = cw[d] * ihc;
+      ptcF[d] = (d == c) ? -A.lambda * det * ih[d] : 0.0;
+    }
+  }
+  (void)Pc; (void)Qc; (void)ptcF;
 
   // gather (constrained DoFs read as zero)
   if (HAS_U && GATHER) {
@@ -395,7 +418,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
           }
 #pragma unroll
           for (int dd = 0; dd < DIM; ++dd) d[dd][x] = g[dd];
-        } else {
+        } else if (!FOLD) {
 #pragma unroll
           for (int dd = 0; dd < DIM; ++dd) d[dd][x] *= ih[dd];
         }
@@ -435,7 +458,8 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
 #pragma unroll
         for (int dd = 0; dd < DIM; ++dd) {
           grow[dd] = d[dd][x];
-          t[dd] = d[dd][x] + ex.get(x, dd, c);
+          const double got = ex.get(x, dd, c);
+          t[dd] = FOLD ? fma(Pc[dd], d[dd][x], Qc[dd] * got) : d[dd][x] + got;
         }
         (void)grow;
         double fdiv = 0.0, div = 0.0;
@@ -495,7 +519,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
         } else {
 #pragma unroll
           for (int dd = 0; dd < DIM; ++dd) {
-            double F = (cw[dd] * f) * t[dd];
+            double F = FOLD ? f * t[dd] : (cw[dd] * f) * t[dd];
             if (COMP) F = fma(-compc[dd], fdiv, F);
             if (HAS_P) F = fma(-lamc[dd], wq * pq[x], F);
             if (NEWTON && A.nw_on) {
@@ -509,7 +533,7 @@ __device__ __forceinline__ void cell_compute(const CellArgs &A, const int cell, 
           if (OP == KOP_STOKES) {
             double s = 0.0;
 #pragma unroll
-            for (int dd = 0; dd < DIM; ++dd) s = fma(ptc[dd], t[dd], s);
+            for (int dd = 0; dd < DIM; ++dd) s = FOLD ? fma(ptcF[dd], grow[dd], s) : fma(ptc[dd], t[dd], s);
             pt[x] = wq * s;
             if (NEWTON && A.dil_lhs) {
               const size_t q = (size_t)(base + x);

@@ -668,7 +668,16 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
     double G[NV], pout[NP];
     AGMG_STAMP(1);
     WaveXch<DIM> ex{xb, lane, j};
+#if AGMG_ABLATE & 64
+    // (diagnostic: no cell arithmetic)
+#pragma unroll
+    for (int a = 0; a < NV; ++a) G[a] = HAS_U ? u[a] : 1.0;
+#pragma unroll
+    for (int b = 0; b < NP; ++b) pout[b] = 0.0;
+    (void)ex;
+#else
     cell_compute<DIM, OP, COMP, PERQ, ETA_LDS, false, GEN>(A, cell, c, j, lane, ex, G, pout, eta_tile, u);
+#endif
     AGMG_STAMP(2);
     double *my = wtile + lane;
 #pragma unroll
