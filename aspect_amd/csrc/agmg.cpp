@@ -1651,20 +1651,30 @@ int multi_axpy(agmg_ctx *c, double *y, const std::vector<const double *> &xs, co
 }
 
 // orthogonalise w against V[0..j] (classical Gram-Schmidt, fused dots, one re-orthogonalisation);
-// h[0..j] receives the coefficients, h[j+1] the norm of the remainder
+// h[0..j] receives the coefficients, h[j+1] the norm of the remainder.  Two reductions (= two host
+// waits, two all-reduces in distributed contexts) per call: the second pass also carries w . w, and
+// with V orthonormal |w - V c|^2 = w . w - |c|^2, where the c of the second pass are rounding-sized
 int orthogonalize(agmg_ctx *c, double *w, const std::vector<double *> &V, int j, const agmg_ctx::Span &sp, std::vector<double> &h) {
   const size_t n = sp.n;
   std::vector<const double *> vs(V.begin(), V.begin() + j + 1);
-  std::vector<double> hh(j + 1), neg(j + 1);
+  std::vector<double> hh(j + 2), neg(j + 1);
   h.assign(j + 2, 0.0);
-  for (int pass = 0; pass < 2; ++pass) {
-    CHECK(c->dots(w, vs, sp, hh.data()));
-    for (int i = 0; i <= j; ++i) { h[i] += hh[i]; neg[i] = -hh[i]; }
-    CHECK(multi_axpy(c, w, vs, neg, n));
+  CHECK(c->dots(w, vs, sp, hh.data()));
+  for (int i = 0; i <= j; ++i) { h[i] += hh[i]; neg[i] = -hh[i]; }
+  CHECK(multi_axpy(c, w, vs, neg, n));
+  std::vector<const double *> vw(vs);
+  vw.push_back(w);
+  CHECK(c->dots(w, vw, sp, hh.data()));
+  double ww = hh[j + 1], corr = 0.0;
+  for (int i = 0; i <= j; ++i) { h[i] += hh[i]; neg[i] = -hh[i]; corr += hh[i] * hh[i]; }
+  CHECK(multi_axpy(c, w, vs, neg, n));
+  if (!(corr <= 1e-8 * ww)) {   // (the basis has lost orthogonality, or w lies in its span: measure the remainder)
+    double s;
+    CHECK(c->norm(w, sp, &s));
+    h[j + 1] = s;
+  } else {
+    h[j + 1] = std::sqrt(ww - corr);
   }
-  double s;
-  CHECK(c->norm(w, sp, &s));
-  h[j + 1] = s;
   return 0;
 }
 
