@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--refinement", type=int, default=5, help="configs[1]: convection_box_3d, global refinement 5")
     ap.add_argument("--large-refinement", type=int, default=7,
                     help="extra A-block roofline point on a level that fills the chip (0 = skip)")
+    ap.add_argument("--scale-refinement", type=int, default=6,
+                    help="N > 1: also time the distributed Stokes vmult and solve with this refinement per GPU, next to "
+                         "the same cube on one GPU (0 = skip); `value` stays configs[1] per GPU for every N")
     ap.add_argument("--config3-refinement", type=int, default=6,
                     help="also solve configs[2] (nsinker, 8 sinkers, ratio 1e6) at this refinement (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -103,14 +106,14 @@ def main():
 
     transport_name = ""
 
-    def distributed_setup():
+    def distributed_setup(refinement=None):
         nonlocal transport_name
         from aspect_amd import partition
         from aspect_amd.parallel import RcclTransport, Transport
         reps = {2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}.get(world)
         if reps is None:
             raise ValueError(f"no subdomain layout for {world} ranks")
-        g = cases.convection_box(3, args.refinement)
+        g = cases.convection_box(3, refinement or args.refinement)
         g.reps, g.extents = reps, [float(r) for r in reps]
         g.build()
         loc = partition.LocalProblem(g, rank, world)
@@ -243,6 +246,55 @@ def main():
                       "fp64_frac": fl.n_cells * A_FLOP_PER_CELL / tl / 1e12 / FP64_PEAK_TFLOPS}
         sl.close()
 
+    # ---------------------------------------------------------------- N > 1: a larger cube per GPU (less latency-bound
+    # than configs[1]) through the same distributed path, and the same cube on one GPU beside it
+    scale_large = None
+    if world > 1 and args.scale_refinement:
+        failed, err = 0.0, ""
+        try:
+            loc2, solver2, fin2, src2_h, nu2, np2 = distributed_setup(args.scale_refinement)
+            src2 = torch.from_numpy(src2_h).to(dev)
+            dst2 = torch.empty_like(src2)
+
+            def step2():
+                if lib.vmult_device(solver2.ctx, capi.OP_STOKES, capi.ACTIVE, dst2.data_ptr(), src2.data_ptr()):
+                    raise RuntimeError(lib.last_error().decode())
+            for _ in range(3):
+                step2()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step2()
+            torch.cuda.synchronize()
+            barrier()
+            dt2 = max_over_ranks(time.perf_counter() - t0) / 20
+            _, _, _ = solver2.solve(allow_failure=True)
+            _, rep_l, rc_l = solver2.solve(allow_failure=True)
+            solve2 = max_over_ranks(rep_l.solve_seconds)
+            solver2.close()
+            # the same cube alone on this rank's GPU
+            p1 = cases.convection_box(3, args.scale_refinement).build()
+            s1 = capi.Solver(lib, p1, device=local_rank)
+            t1 = max_over_ranks(s1.bench_vmult(capi.OP_STOKES, capi.ACTIVE, 20))
+            _, _, _ = s1.solve(allow_failure=True)
+            _, rep_1, _ = s1.solve(allow_failure=True)
+            solve1 = max_over_ranks(rep_1.solve_seconds)
+            f1 = p1.hier.finest
+            s1.close()
+            scale_large = {"workload": f"convection_box_3d r{args.scale_refinement} per GPU ({fin2.n_cells} cells, "
+                                       f"{int(nu2)}+{int(np2)} DoFs per GPU)",
+                           "stokes_vmult_us": 1e6 * dt2, "gdofs": world * (nu2 + np2) / dt2 / 1e9,
+                           "solve_seconds": solve2, "gmres_iterations": f"{rep_l.n_cheap_iterations}+{rep_l.n_expensive_iterations}",
+                           "solve_status": rc_l,
+                           "one_gpu_same_cube": {"stokes_vmult_us": 1e6 * t1, "gdofs": (f1.n_dofs_v + f1.n_dofs_p) / t1 / 1e9,
+                                                 "solve_seconds": solve1,
+                                                 "gmres_iterations": f"{rep_1.n_cheap_iterations}+{rep_1.n_expensive_iterations}"}}
+        except Exception as e:  # noqa: BLE001
+            failed, err = 1.0, repr(e)
+        if max_over_ranks(failed) > 0:
+            scale_large = {"error": f"rank {rank}: {err or 'failed on another rank'}"}
+
     # ---------------------------------------------------------------- configs[2]: nsinker, 8 sinkers, ratio 1e6, r6
     config3 = None
     if args.config3_refinement and rank == 0 and world == 1:
@@ -288,7 +340,8 @@ def main():
                 "config": {"workload": f"cookbooks/convection_box_3d, global refinement {args.refinement}, "
                                        f"{fin.n_cells} cells, {int(nu)}+{int(npd)} DoFs per GPU, per-q viscosity tables",
                            "parallelism": parallelism},
-                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, "config3_nsinker": config3, **extra}
+                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, "config3_nsinker": config3, "weak_scaling_larger_cube": scale_large,
+                **extra}
         print(json.dumps(line))
     ranks.close()
 
