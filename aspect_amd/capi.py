@@ -295,6 +295,8 @@ class Solver:
         t = np.ascontiguousarray(table, dtype=np.float64)
         cd = CellData()
         cd.is_compressible = is_compressible
+        if l == ACTIVE:   # (operators.Tvmult: the Stokes operator stops being symmetric)
+            self.unsymmetric_newton = newton is not None and not symmetrize
         if newton is not None:
             nt = [np.ascontiguousarray(a, dtype=np.float64) for a in newton]
             cd.enable_newton_derivatives = 1

@@ -25,7 +25,14 @@ class _Operator:
     def vmult_add(self, dst, src):
         dst += self.handler.solver.vmult(self.which, src, self.level)
 
-    def Tvmult(self, dst, src):          # all four operators are symmetric or used via vmult only
+    def Tvmult(self, dst, src):
+        """Transpose application.  The A block, the mass operator and the plain Stokes operator are symmetric
+        (vmult serves); the Stokes operator with unsymmetrised Newton derivatives is not, and neither the
+        reference (MatrixFreeOperators::Base::Tvmult is never called on this path) nor the C ABI applies its
+        transpose; B^T is only used through vmult as well."""
+        newton = getattr(self.handler.solver, "unsymmetric_newton", False)
+        if self.which == capi.OP_BT or (self.which == capi.OP_STOKES and newton):
+            raise NotImplementedError("Tvmult of an unsymmetric operator is not part of the path (nor of the reference's)")
         self.vmult(dst, src)
 
 
