@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <array>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 #include <chrono>
 #include <cmath>
@@ -371,85 +372,119 @@ void agmg_ctx::free_level(DeviceLevel &l) {
 // cells touching it lie in one block.
 // Distributed levels: ghost nodes and owned nodes another rank ghosts (`send_nodes`) are always
 // "shared": their sums wait for / feed the ghost exchange in the fix-up kernel.
+// host-side table building runs on a few threads (std::thread: no OpenMP runtime next to the caller's);
+// AGMG_HOST_THREADS overrides the default of min(16, hardware threads)
+static int host_threads() {
+  static const int n = [] {
+    const char *e = getenv("AGMG_HOST_THREADS");
+    int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return t < 1 ? 1 : t;
+  }();
+  return n;
+}
+template <class F> static void parallel_for(const size_t n, const F &fn) {   // fn(begin, end, thread)
+  const int T = (int)std::min<size_t>((size_t)host_threads(), std::max<size_t>(1, n / 1024));
+  if (T <= 1) { fn((size_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T, t); });
+  for (auto &x : th) x.join();
+}
+
 int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                                  const std::vector<uint32_t> &send_nodes) {
   BlockTables &bt = lv.bt;
   const int dim = lv.dim, NV = ipow(3, dim), nn = lv.n_nodes_v;
   const int cpw = cells_per_wave(dim), bc = cpw * WAVES_PER_BLOCK;
   const int nb = (lv.n_cells + bc - 1) / bc;
-  // pass 1: number of blocks touching each node
-  std::vector<int> last(nn, -1);
-  std::vector<uint8_t> nblk(nn, 0);
-  for (int b = 0; b < nb; ++b) {
-    const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
-    for (int cell = c0; cell < c1; ++cell)
-      for (int a = 0; a < NV; ++a) {
-        const uint32_t node = hl.cnv[(size_t)cell * NV + a];
-        if (last[node] != b) { last[node] = b; if (nblk[node] < 255) ++nblk[node]; }
-      }
-  }
-  for (int node = lv.n_owned_v; node < nn; ++node) nblk[node] = std::max<uint8_t>(nblk[node], 2);
-  for (uint32_t node : send_nodes) nblk[node] = std::max<uint8_t>(nblk[node], 2);
-  // pass 2: per block unique nodes (exclusive first, each group ascending) and up to 8 LDS
-  // slots per node, in (cell, local dof) order.  Tables have a fixed stride max_u per block.
+  // pass 1: the sorted unique nodes of every block; number of blocks touching each node
   std::vector<std::vector<uint32_t>> bl_nodes(nb);
+  std::vector<uint8_t> nblk(nn, 0);
+  parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
+    for (size_t b = b0; b < b1; ++b) {
+      const size_t c0 = b * bc, c1 = std::min(c0 + (size_t)bc, (size_t)lv.n_cells);
+      std::vector<uint32_t> &u = bl_nodes[b];
+      u.assign(hl.cnv.begin() + c0 * NV, hl.cnv.begin() + c1 * NV);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      for (uint32_t node : u) {
+        uint8_t &k = nblk[node];
+        if (__atomic_load_n(&k, __ATOMIC_RELAXED) < 255) __atomic_fetch_add(&k, (uint8_t)1, __ATOMIC_RELAXED);
+      }
+    }
+  });
+  // shared = touched by several blocks; on distributed levels also every ghost node and every owned
+  // node another rank ghosts (the count of local blocks stays in nblk)
+  std::vector<uint8_t> shared(nn, 0);
+  parallel_for((size_t)nn, [&](size_t i0, size_t i1, int) {
+    for (size_t i = i0; i < i1; ++i) shared[i] = nblk[i] > 1 || (int)i >= lv.n_owned_v;
+  });
+  for (uint32_t node : send_nodes) shared[node] = 1;
+  // pass 2: per block exclusive nodes first, then the shared ones (each group ascending)
   std::vector<uint32_t> blk_hdr((size_t)nb * 4, 0);
-  std::vector<int> lid_of(nn, -1);
-  std::fill(last.begin(), last.end(), -1);
-  std::vector<uint32_t> ex, sh;
-  std::vector<uint32_t> sh_count(nn, 0);
+  std::vector<uint8_t> too_big(nb, 0);
+  parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
+    std::vector<uint32_t> sh;
+    for (size_t b = b0; b < b1; ++b) {
+      std::vector<uint32_t> &u = bl_nodes[b];
+      sh.clear();
+      size_t ne = 0;
+      for (uint32_t node : u) { if (shared[node]) sh.push_back(node); else u[ne++] = node; }
+      std::copy(sh.begin(), sh.end(), u.begin() + ne);
+      if ((int)u.size() > bc * NV / 2) too_big[b] = 1;
+      blk_hdr[b * 4 + 0] = (uint32_t)u.size();
+      blk_hdr[b * 4 + 1] = (uint32_t)ne;
+    }
+  });
   size_t nslots = 0;
   int max_u = 0;
-  std::vector<std::pair<uint32_t, uint32_t>> sh_pairs;  // (node, slot position)
   for (int b = 0; b < nb; ++b) {
-    const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
-    ex.clear(); sh.clear();
-    for (int cell = c0; cell < c1; ++cell)
-      for (int a = 0; a < NV; ++a) {
-        const uint32_t node = hl.cnv[(size_t)cell * NV + a];
-        if (last[node] != b) { last[node] = b; (nblk[node] > 1 ? sh : ex).push_back(node); }
-      }
-    std::sort(ex.begin(), ex.end());
-    std::sort(sh.begin(), sh.end());
-    const int U = (int)(ex.size() + sh.size());
-    if (U > bc * NV / 2) return 0;  // (degenerate meshes) kernel's per-thread metadata bound: keep the slot path
-    max_u = std::max(max_u, U);
-    blk_hdr[(size_t)b * 4 + 0] = (uint32_t)U;
-    blk_hdr[(size_t)b * 4 + 1] = (uint32_t)ex.size();
+    if (too_big[b]) return 0;  // (degenerate meshes) kernel's per-thread metadata bound: keep the slot path
+    max_u = std::max(max_u, (int)blk_hdr[(size_t)b * 4]);
     blk_hdr[(size_t)b * 4 + 2] = (uint32_t)nslots;
-    bl_nodes[b] = ex;
-    bl_nodes[b].insert(bl_nodes[b].end(), sh.begin(), sh.end());
-    for (uint32_t node : sh) {
-      sh_pairs.emplace_back(node, (uint32_t)nslots++);
-      ++sh_count[node];
-    }
+    nslots += blk_hdr[(size_t)b * 4] - blk_hdr[(size_t)b * 4 + 1];
   }
+  // per block: node words, local ids of the cells' nodes, up to 8 LDS slots per node in (cell, local dof) order
   const int wtile = blk_wave_tile(dim);
   const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile * 8);  // entries are LDS byte offsets
   std::vector<uint32_t> unodes((size_t)nb * max_u, 0);
   std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot), lidT((size_t)LID_ROW * lv.cstride, 0);
-  std::vector<uint8_t> cnt;
-  for (int b = 0; b < nb; ++b) {
-    const int c0 = b * bc, c1 = std::min(c0 + bc, lv.n_cells);
-    const size_t m0 = (size_t)b * max_u;
-    const int U = (int)bl_nodes[b].size();
-    for (int l = 0; l < U; ++l) {
-      const uint32_t node = bl_nodes[b][l];
-      lid_of[node] = l;
-      unodes[m0 + l] = node | ((uint32_t)cmv[node] << 29);
-    }
-    cnt.assign(U, 0);
-    for (int cell = c0; cell < c1; ++cell) {
-      const int w = (cell - c0) / cpw, jj = (cell - c0) % cpw;
-      for (int a = 0; a < NV; ++a) {
-        const int l = lid_of[hl.cnv[(size_t)cell * NV + a]];
-        lidT[(size_t)cell * LID_ROW + a] = (uint16_t)l;
-        if (cnt[l] >= 8) return 0;  // node of valence > 8 inside one block: keep the slot path
-        uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)((w * wtile + a * BLK_SLOT_ROW + jj * dim) * 8);
+  std::vector<uint8_t> valence_ok(nb, 1);
+  parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
+    std::vector<uint8_t> cnt;
+    for (size_t b = b0; b < b1; ++b) {
+      const size_t c0 = b * bc, c1 = std::min(c0 + (size_t)bc, (size_t)lv.n_cells);
+      const size_t m0 = b * max_u;
+      const std::vector<uint32_t> &u = bl_nodes[b];
+      const int U = (int)u.size(), ne = (int)blk_hdr[b * 4 + 1];
+      for (int l = 0; l < U; ++l) unodes[m0 + l] = u[l] | ((uint32_t)cmv[u[l]] << 29);
+      cnt.assign(U, 0);
+      for (size_t cell = c0; cell < c1; ++cell) {
+        const int w = (int)(cell - c0) / cpw, jj = (int)(cell - c0) % cpw;
+        for (int a = 0; a < NV; ++a) {
+          const uint32_t node = hl.cnv[cell * NV + a];
+          const auto first = shared[node] ? u.begin() + ne : u.begin(), last = shared[node] ? u.end() : u.begin() + ne;
+          const int l = (int)(std::lower_bound(first, last, node) - u.begin());
+          lidT[cell * LID_ROW + a] = (uint16_t)l;
+          if (cnt[l] >= 8) { valence_ok[b] = 0; continue; }  // node of valence > 8 inside one block
+          uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)((w * wtile + a * BLK_SLOT_ROW + jj * dim) * 8);
+        }
       }
     }
-    std::vector<uint32_t>().swap(bl_nodes[b]);
+  });
+  for (int b = 0; b < nb; ++b) if (!valence_ok[b]) return 0;   // keep the slot path
+  // slots of the shared nodes, block by block
+  std::vector<uint32_t> sh_count(nn, 0);
+  std::vector<std::pair<uint32_t, uint32_t>> sh_pairs;  // (node, slot position)
+  sh_pairs.reserve(nslots + send_nodes.size());
+  for (int b = 0; b < nb; ++b) {
+    const std::vector<uint32_t> &u = bl_nodes[b];
+    size_t slot = blk_hdr[(size_t)b * 4 + 2];
+    for (size_t l = blk_hdr[(size_t)b * 4 + 1]; l < u.size(); ++l) {
+      sh_pairs.emplace_back(u[l], (uint32_t)slot++);
+      ++sh_count[u[l]];
+    }
   }
+  std::vector<std::vector<uint32_t>>().swap(bl_nodes);
   // remote partial sums: entry k of the receive buffer belongs to owned node send_nodes[k]
   for (size_t k = 0; k < send_nodes.size(); ++k) {
     sh_pairs.emplace_back(send_nodes[k], (uint32_t)(nslots + k));
@@ -2002,8 +2037,23 @@ void agmg_destroy(agmg_ctx *c) {
   delete c;
 }
 
+namespace {
+// AGMG_TIMING=1: wall time of the host-side steps of agmg_set_level on stderr (per mesh change)
+struct StepTimer {
+  const bool on = getenv("AGMG_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what, int level) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[agmg timing] level %d %-28s %8.1f ms\n", level, what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   if (!c) { set_error("null context"); return -1; }
+  StepTimer tm;
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   if (level == AGMG_ACTIVE) {
     if (d) { set_error("a separate active-mesh table is not supported: the active mesh must alias the finest level (uniformly refined meshes; adaptive = SURVEY.md 8f1)"); return -2; }
@@ -2090,6 +2140,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
       if (level == c->nl() - 1) c->gid_fin_h[vel] = g;
     }
   }
+  tm.lap("copy + exchange plan", level);
   for (int vel = 0; vel < 2; ++vel) {
     const int nloc = vel ? NV : NP, nn = vel ? lv.n_nodes_v : lv.n_nodes_p;
     const std::vector<uint32_t> &cn = vel ? hl.cnv : hl.cnp;
@@ -2097,13 +2148,19 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     const std::vector<uint32_t> &snh = c->send_nodes_h[vel ? 0 : 1][level];
     std::vector<uint32_t> T((size_t)nloc * cs);
     std::vector<uint32_t> ptr((size_t)nn + 1, 0), list((size_t)lv.n_cells * nloc + snh.size());
-    for (int cell = 0; cell < lv.n_cells; ++cell)
-      for (int a = 0; a < nloc; ++a) {
-        const uint32_t node = cn[(size_t)cell * nloc + a];
-        if ((int)node >= nn) { set_error(vel ? "cell_nodes_v out of range" : "cell_nodes_p out of range"); return -1; }
-        T[(size_t)a * cs + cell] = node | ((uint32_t)cm[node] << 29);
-        ++ptr[node + 1];
-      }
+    {
+      std::vector<uint8_t> bad(64, 0);
+      parallel_for((size_t)lv.n_cells, [&](size_t c0, size_t c1, int t) {
+        for (size_t cell = c0; cell < c1; ++cell)
+          for (int a = 0; a < nloc; ++a) {
+            const uint32_t node = cn[cell * nloc + a];
+            if ((int)node >= nn) { bad[t & 63] = 1; continue; }
+            T[(size_t)a * cs + cell] = node | ((uint32_t)cm[node] << 29);
+          }
+      });
+      for (uint8_t f : bad) if (f) { set_error(vel ? "cell_nodes_v out of range" : "cell_nodes_p out of range"); return -1; }
+    }
+    for (size_t k = 0, ne = (size_t)lv.n_cells * nloc; k < ne; ++k) ++ptr[cn[k] + 1];
     for (size_t cell = lv.n_cells; cell < cs; ++cell)
       for (int a = 0; a < nloc; ++a) T[(size_t)a * cs + cell] = T[(size_t)a * cs + lv.n_cells - 1];
     for (uint32_t node : snh) ++ptr[node + 1];   // remote partial sums (receive buffer entries)
@@ -2126,25 +2183,31 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
         const int W = NV;   // 3^dim
         const size_t npad = ((size_t)nn + 63) / 64 * 64;
         std::vector<uint32_t> col((size_t)W * npad);
-        bool ok = true;
-        uint32_t nb[64];
-        for (int i = 0; i < nn && ok; ++i) {
-          int cnt = 0;
-          for (uint32_t k = ptr[i]; k < ptr[i + 1] && ok; ++k) {
-            const size_t cell = list[k] % cs;
-            for (int a = 0; a < nloc; ++a) {
-              const uint32_t node = cn[cell * nloc + a];
-              int t = 0;
-              while (t < cnt && nb[t] != node) ++t;
-              if (t == cnt) {
-                if (cnt == W) { ok = false; break; }
-                nb[cnt++] = node;
+        std::vector<uint8_t> irregular(64, 0);
+        parallel_for((size_t)nn, [&](size_t i0, size_t i1, int t) {
+          uint32_t nb[64];
+          for (size_t i = i0; i < i1; ++i) {
+            int cnt = 0;
+            bool ok_i = true;
+            for (uint32_t k = ptr[i]; k < ptr[i + 1] && ok_i; ++k) {
+              const size_t cell = list[k] % cs;
+              for (int a = 0; a < nloc; ++a) {
+                const uint32_t node = cn[cell * nloc + a];
+                int q = 0;
+                while (q < cnt && nb[q] != node) ++q;
+                if (q == cnt) {
+                  if (cnt == W) { ok_i = false; break; }
+                  nb[cnt++] = node;
+                }
               }
             }
+            if (!ok_i) { irregular[t & 63] = 1; continue; }
+            std::sort(nb, nb + cnt);
+            for (int k = 0; k < W; ++k) col[(size_t)k * npad + i] = k < cnt ? nb[k] : (uint32_t)i;
           }
-          std::sort(nb, nb + cnt);
-          for (int k = 0; k < W; ++k) col[(size_t)k * npad + i] = k < cnt ? nb[k] : (uint32_t)i;
-        }
+        });
+        bool ok = true;
+        for (uint8_t f : irregular) if (f) ok = false;
         for (size_t i = nn; i < npad; ++i)
           for (int k = 0; k < W; ++k) col[(size_t)k * npad + i] = 0;
         if (ok) {
@@ -2159,6 +2222,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     else { CHECK(c->upload(&lv.cnpT, T)); CHECK(c->upload(&lv.pull_ptr_p, ptr)); CHECK(c->upload(&lv.pull_list_p, list)); CHECK(c->upload(&lv.cmask_p, cmp)); }
     lv.bytes_tables += (T.size() + ptr.size() + list.size()) * 4;
     lv.bytes_constraints += cm.size();
+    tm.lap(vel ? "velocity cell/pull tables" : "pressure tables + ELL columns", level);
   }
   lv.geom = d->geometry_kind;
   const int NQ = NV;
@@ -2191,7 +2255,9 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     hl.parent.assign(d->parent_cell, d->parent_cell + lv.n_cells);
     hl.child.assign(d->child_index, d->child_index + lv.n_cells);
   }
+  tm.lap("geometry", level);
   CHECK(c->build_block_tables(lv, hl, cmv, c->send_nodes_h[0][level]));
+  tm.lap("block tables", level);
   lv.bytes_tables += lv.bt.bytes;
   if (c->use_bricks) {
     CHECK(c->build_brick_tables(lv, hl, cmv));
