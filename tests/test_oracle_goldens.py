@@ -263,6 +263,50 @@ def test_periodic_box_tables_transfer_and_solve():
     s.close()
 
 
+def test_periodic_box_free_slip_a_block_is_singular_on_every_level():
+    """Why the 53+0 of tests/periodic_box_gmg is not a number a restatement can be pinned on:
+    with periodicity in x and free slip on top and bottom the x-translation is in the kernel of the A
+    block on EVERY level (the deck removes it from the solution afterwards: "Remove nullspace = net x
+    translation").  The coarse "solver" is a Chebyshev iteration of degree 8 whose range comes from a CG
+    estimate of the largest eigenvalue of D^-1 A with eig_cg_n_iterations = 100 (local_smoothing.cc:934-936,
+    deal.II runs those steps under an IterationNumberControl): on the 12-DoF coarse level the Krylov space is
+    exhausted after at most 9 steps, the start vector has a component in the kernel that CG cannot remove, and
+    the remaining ~90 steps of the Lanczos recurrence divide rounding noise by rounding noise.  The estimate,
+    and with it every coarse solve and the iteration count, belongs to one particular floating-point sequence.  The
+    no-slip variant, where A is definite, is the one whose solve is checked above."""
+    p = cases.periodic_box_2d(5).build()
+    s = pyoracle.solver(p)
+    rng = np.random.Generator(np.random.PCG64(3))
+    for level in list(range(p.hier.n_levels)) + [capi.ACTIVE]:
+        lev = p.hier.finest if level == capi.ACTIVE else p.hier.levels[level]
+        n = s.size(capi.OP_A, level)
+        t = np.zeros(n)
+        t[0::2] = 1.0                                   # u = (1, 0) at every node
+        con = np.asarray(lev.constrained_dofs_v(), dtype=bool)
+        assert not con[0::2].any()                      # free slip leaves u_x free
+        scale = np.linalg.norm(s.vmult(capi.OP_A, rng.uniform(-1, 1, n) * ~con, level))
+        assert np.linalg.norm(s.vmult(capi.OP_A, t, level)) <= 1e-12 * scale
+    # the coarse level as a dense matrix: one eigenvalue of D^-1 A is zero to rounding
+    n0 = s.size(capi.OP_A, 0)
+    A0 = np.column_stack([s.vmult(capi.OP_A, e, 0) for e in np.eye(n0)])
+    free = np.flatnonzero(~np.asarray(p.hier.levels[0].constrained_dofs_v(), dtype=bool))
+    A0 = A0[np.ix_(free, free)]
+    ev = np.sort(np.linalg.eigvalsh(A0 / np.sqrt(np.outer(np.diag(A0), np.diag(A0)))))
+    assert abs(ev[0]) <= 1e-12 * ev[-1] and ev[1] > 1e-3 * ev[-1]
+    s.close()
+    # the well-posed variant has no such mode
+    q = cases.periodic_box_2d(5, no_slip_walls=True).build()
+    s = pyoracle.solver(q)
+    n0 = s.size(capi.OP_A, 0)
+    B0 = np.column_stack([s.vmult(capi.OP_A, e, 0) for e in np.eye(n0)])
+    free = np.flatnonzero(~np.asarray(q.hier.levels[0].constrained_dofs_v(), dtype=bool))
+    if free.size:
+        B0 = B0[np.ix_(free, free)]
+        evb = np.sort(np.linalg.eigvalsh(B0 / np.sqrt(np.outer(np.diag(B0), np.diag(B0)))))
+        assert evb[0] > 1e-3 * evb[-1]
+    s.close()
+
+
 @pytest.mark.parametrize("make", [
     lambda: cases.nsinker_box(1, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE),
     lambda: cases.solcx(2),
