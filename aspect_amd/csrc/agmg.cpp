@@ -445,7 +445,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   }
   // per block: node words, local ids of the cells' nodes, up to 8 LDS slots per node in (cell, local dof) order
   const int wtile = blk_wave_tile(dim);
-  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile * 8);  // entries are LDS byte offsets
+  const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile);  // entries are LDS slot indices (doubles)
   std::vector<uint32_t> unodes((size_t)nb * max_u, 0);
   std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot), lidT((size_t)LID_ROW * lv.cstride, 0);
   std::vector<uint8_t> valence_ok(nb, 1);
@@ -466,7 +466,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
           const int l = (int)(std::lower_bound(first, last, node) - u.begin());
           lidT[cell * LID_ROW + a] = (uint16_t)l;
           if (cnt[l] >= 8) { valence_ok[b] = 0; continue; }  // node of valence > 8 inside one block
-          uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)((w * wtile + a * BLK_SLOT_ROW + jj * dim) * 8);
+          uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)(w * wtile + a * BLK_SLOT_ROW + jj * dim);
         }
       }
     }

@@ -23,7 +23,10 @@ namespace agmg {
 void set_error(const std::string &msg);
 
 constexpr uint32_t NODE_MASK = 0x1FFFFFFFu;  // low 29 bits: node index; high 3 bits: constraint bits
-constexpr int WAVES_PER_BLOCK = 4;
+#ifndef AGMG_WAVES_PER_BLOCK
+#define AGMG_WAVES_PER_BLOCK 4
+#endif
+constexpr int WAVES_PER_BLOCK = AGMG_WAVES_PER_BLOCK;
 // cell kernels: one lane per (cell, velocity component); 21 cells (3-D) or 32
 // cells (2-D) per 64-lane wavefront
 constexpr int cells_per_wave(int dim) { return 64 / dim; }

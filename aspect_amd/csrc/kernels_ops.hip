@@ -478,7 +478,7 @@ template <int DIM> struct BlkLds {
 
 // node-owner sums of the block kernel, specialised on the epilogue (EPI) so the item loop has no
 // switch: one thread per node of the block and all DIM components; the 8 slot entries of a node
-// are LDS byte offsets (missing ones point at the zero triple)
+// are LDS slot indices in doubles (missing ones point at the zero triple)
 template <int DIM, int EPI>
 __device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *l_ent, const uint32_t *l_unodes,
                                               const int U, const int nex, const EpiArgs &E, double *slots_sh,
@@ -502,7 +502,7 @@ __device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t off = (k & 1) ? (ew[k >> 1] >> 16) : (ew[k >> 1] & 0xFFFFu);
-      const double *p = reinterpret_cast<const double *>(slots_c + off);
+      const double *p = reinterpret_cast<const double *>(slots_c) + off;
 #pragma unroll
       for (int cc = 0; cc < DIM; ++cc) sum[i][cc] += p[cc];
     }
