@@ -274,6 +274,29 @@ def test_solve_iterations_and_solution(pair):
     assert relerr(xg[:nu], xo[:nu]) < (1e-4 if rhs_norm < 1e6 else 5e-3)
 
 
+@pytest.mark.parametrize("make", [
+    lambda: cases.nsinker_box(2, n_sinkers=4, ratio=1e4, tol=1e-12, n_cheap=400),
+    lambda: cases.solcx(4, n_cheap=400),
+])
+def test_solutions_agree_when_both_solve_tightly(hip_lib, oracle_lib, make):
+    """The 1e-4 / 5e-3 agreement of the test above is what stopping at the deck's tolerance leaves.  Solved
+    to 1e-12 of the initial residual, the HIP and the oracle solutions are the same vector to 1e-8."""
+    p = make()
+    p.tol = 1e-12
+    p.build()
+    g, o = capi.Solver(hip_lib, p), capi.Solver(oracle_lib, p)
+    try:
+        xg, rg, rcg = g.solve()
+        xo, ro, rco = o.solve()
+        assert rcg == 0 and rco == 0
+        assert abs(rg.n_cheap_iterations - ro.n_cheap_iterations) <= 1
+        nu = p.hier.finest.n_dofs_v
+        assert relerr(xg[:nu], xo[:nu]) < 1e-8
+        assert relerr(xg[nu:] - xg[nu:].mean(), xo[nu:] - xo[nu:].mean()) < 1e-7
+    finally:
+        g.close(); o.close()
+
+
 def test_device_coarse_level_matches_host_coarse(hip_lib):
     """coarse_on_host = 0 runs the level-0 Chebyshev 'solver' on the device: same V-cycle."""
     p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4).build()
