@@ -473,26 +473,22 @@ template <int DIM> struct BlkLds {
   static_assert(KDims<DIM>::XB + KDims<DIM>::NV * KDims<DIM>::CPW <= WTILE && KDims<DIM>::NV * BLK_SLOT_ROW <= WTILE,
                 "exchange + eta tiles and the slot tile must fit the wave's tile");
   __host__ __device__ static size_t unodes_off(int max_u) { return slots + (size_t)max_u * 16; }
-  __host__ __device__ static size_t total(int max_u) { return unodes_off(max_u) + (size_t)max_u * 4; }
+  __host__ __device__ static size_t total(int max_u) { return unodes_off(max_u); }   // (the node words live in registers)
 };
 
 // node-owner sums of the block kernel, specialised on the epilogue (EPI) so the item loop has no
 // switch: one thread per node of the block and all DIM components; the 8 slot entries of a node
 // are LDS slot indices in doubles (missing ones point at the zero triple)
 template <int DIM, int EPI>
-__device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *l_ent, const uint32_t *l_unodes,
+__device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *l_ent, const uint32_t *nd /* [MAXU_PT] */,
                                               const int U, const int nex, const EpiArgs &E, double *slots_sh,
                                               const size_t sbase) {
   constexpr int NT = 64 * WAVES_PER_BLOCK;
   constexpr int MAXU_PT = (KDims<DIM>::CPW * WAVES_PER_BLOCK * KDims<DIM>::NV / 2 + NT - 1) / NT;
+  // (thread t finishes the nodes t, t + NT, ...: their words are the ones it holds in registers)
   uint4 e4[MAXU_PT];
-  uint32_t nd[MAXU_PT];
 #pragma unroll
-  for (int i = 0; i < MAXU_PT; ++i) {
-    const int lid = min((int)threadIdx.x + i * NT, U - 1);
-    e4[i] = l_ent[lid];
-    nd[i] = l_unodes[lid];
-  }
+  for (int i = 0; i < MAXU_PT; ++i) e4[i] = l_ent[min((int)threadIdx.x + i * NT, U - 1)];
   double sum[MAXU_PT][DIM];
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) {
@@ -551,7 +547,6 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   char *const smem_c = reinterpret_cast<char *>(smem);
   double *const slots = smem;                                      // [wave][WTILE] + zero triple
   uint4 *const l_ent = reinterpret_cast<uint4 *>(smem_c + BlkLds<DIM>::slots);
-  uint32_t *const l_unodes = reinterpret_cast<uint32_t *>(smem_c + BlkLds<DIM>::unodes_off(max_u));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Life of the slot area: (1) copy of the source vector at the block's nodes, gathered from by
   // all waves; (2) per wave: gradient-exchange tile + viscosity tile; (3) per wave: slot tile
@@ -577,19 +572,25 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   const int cell = cell_l < A.n_cells ? cell_l : A.n_cells - 1;
   const size_t cs = (size_t)A.cstride;
   AGMG_STAMP(0);
-  // ---- all global reads of the block are issued here, coalesced.  Block tables (fixed stride
-  // max_u per block: no dependent address) go straight to LDS (LDS-DMA, no registers): wave w
-  // moves entries [i*NT + 64w, +64) of each table, i.e. exactly the ones its own lanes read back
+  // ---- all global reads of the block are issued here, coalesced.  First the node words of the block's
+  // nodes (registers; thread t holds entries t, t + NT, ..., which the host pads with node 0 up to max_u):
+  // the gather of the source vector depends on them, and vector loads return in the order issued, so
+  // it can start as soon as they are back, while the rest of this batch is still in flight.  The slot
+  // entries of the node sums (fixed stride max_u per block: no dependent address) go straight to LDS
+  // (LDS-DMA, no registers): wave w moves entries [i*NT + 64w, +64)
   const size_t mbase = (size_t)blk * max_u;
+  uint32_t m_node[MAXU_PT];
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) {
     const int t = threadIdx.x + i * NT;
-    if (t < max_u) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B.unodes + mbase + t),
-                                       (__attribute__((address_space(3))) void *)(l_unodes + i * NT + wave * 64), 4, 0, 0);
+    m_node[i] = t < max_u ? B.unodes[mbase + t] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXU_PT; ++i) {
+    const int t = threadIdx.x + i * NT;
+    if (t < max_u)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B.uent8 + mbase + t),
                                        (__attribute__((address_space(3))) void *)(l_ent + i * NT + wave * 64), 16, 0, 0);
-    }
   }
   const uint4 hdr = B.blk_hdr[blk];
   const int U = (int)hdr.x, nex = (int)hdr.y;
@@ -620,21 +621,12 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
     }
   }
   if (threadIdx.x < 4) slots[BlkLds<DIM>::ZERO_SLOT + threadIdx.x] = 0.0;
-  // the tables must have landed before this wave reads its own entries (and before the block
-  // barrier publishes them to the other waves)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   double u[NV];
   if (HAS_U) {
     // source vector at the block's nodes -> LDS (one thread per node, constrained entries zeroed)
-    uint32_t m_node[MAXU_PT];
     double sv[MAXU_PT][DIM];
 #pragma unroll
     for (int i = 0; i < MAXU_PT; ++i) {   // all loads first
-      // only this wave's own table entries have provably landed (no barrier yet): entry t, which the
-      // host pads with node 0 up to max_u, never another wave's entry U - 1 -- that one may still be
-      // whatever an earlier kernel left in this LDS and would send the gather to a wild address
-      const int t = (int)threadIdx.x + i * NT;
-      m_node[i] = t < max_u ? l_unodes[t] : 0u;
       const double *sp = A.src_u + (size_t)(m_node[i] & NODE_MASK) * DIM;
 #pragma unroll
       for (int cc = 0; cc < DIM; ++cc) sv[i][cc] = sp[cc];
@@ -648,6 +640,7 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
       }
     }
     AGMG_STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA of the slot entries: not tracked by the compiler)
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < NV; ++a) u[a] = slots[lids[a] * DIM + c];
@@ -689,15 +682,16 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
     }
   }
   AGMG_STAMP(3);
+  if (!HAS_U) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA of the slot entries, see above)
   __syncthreads();
   AGMG_STAMP(4);
 #if AGMG_ABLATE & 128
   if (slots[threadIdx.x] != 12345.678) return;
 #endif
   const size_t sbase = (size_t)hdr.z * DIM;
-  if (E.epi == EPI_CHEB) blk_node_sums<DIM, EPI_CHEB>(smem_c, l_ent, l_unodes, U, nex, E, B.slots_sh, sbase);
-  else if (E.epi == EPI_RESID) blk_node_sums<DIM, EPI_RESID>(smem_c, l_ent, l_unodes, U, nex, E, B.slots_sh, sbase);
-  else blk_node_sums<DIM, EPI_STORE>(smem_c, l_ent, l_unodes, U, nex, E, B.slots_sh, sbase);
+  if (E.epi == EPI_CHEB) blk_node_sums<DIM, EPI_CHEB>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
+  else if (E.epi == EPI_RESID) blk_node_sums<DIM, EPI_RESID>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
+  else blk_node_sums<DIM, EPI_STORE>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
   AGMG_STAMP(5);
 }
 
