@@ -396,26 +396,16 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   const int dim = lv.dim, NV = ipow(3, dim), nn = lv.n_nodes_v;
   const int cpw = cells_per_wave(dim), bc = cpw * WAVES_PER_BLOCK;
   const int nb = (lv.n_cells + bc - 1) / bc;
-  // pass 1: the sorted unique nodes of every block with their valence inside the block (number of
-  // (cell, local dof) pairs that hit them); number of blocks touching each node
-  std::vector<std::vector<uint32_t>> bl_sorted(nb);
-  std::vector<std::vector<uint8_t>> bl_val(nb);
+  // pass 1: the sorted unique nodes of every block; number of blocks touching each node
+  std::vector<std::vector<uint32_t>> bl_nodes(nb);
   std::vector<uint8_t> nblk(nn, 0);
   parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
-    std::vector<uint32_t> all;
     for (size_t b = b0; b < b1; ++b) {
       const size_t c0 = b * bc, c1 = std::min(c0 + (size_t)bc, (size_t)lv.n_cells);
-      all.assign(hl.cnv.begin() + c0 * NV, hl.cnv.begin() + c1 * NV);
-      std::sort(all.begin(), all.end());
-      std::vector<uint32_t> &u = bl_sorted[b];
-      std::vector<uint8_t> &v = bl_val[b];
-      for (size_t k = 0; k < all.size();) {
-        size_t e = k + 1;
-        while (e < all.size() && all[e] == all[k]) ++e;
-        u.push_back(all[k]);
-        v.push_back((uint8_t)std::min<size_t>(e - k, 255));
-        k = e;
-      }
+      std::vector<uint32_t> &u = bl_nodes[b];
+      u.assign(hl.cnv.begin() + c0 * NV, hl.cnv.begin() + c1 * NV);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
       for (uint32_t node : u) {
         uint8_t &k = nblk[node];
         if (__atomic_load_n(&k, __ATOMIC_RELAXED) < 255) __atomic_fetch_add(&k, (uint8_t)1, __ATOMIC_RELAXED);
@@ -423,91 +413,78 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
     }
   });
   // shared = touched by several blocks; on distributed levels also every ghost node and every owned
-  // node another rank ghosts
+  // node another rank ghosts (the count of local blocks stays in nblk)
   std::vector<uint8_t> shared(nn, 0);
   parallel_for((size_t)nn, [&](size_t i0, size_t i1, int) {
     for (size_t i = i0; i < i1; ++i) shared[i] = nblk[i] > 1 || (int)i >= lv.n_owned_v;
   });
   for (uint32_t node : send_nodes) shared[node] = 1;
+  // pass 2: per block exclusive nodes first, then the shared ones (each group ascending)
+  std::vector<uint32_t> blk_hdr((size_t)nb * 4, 0);
+  std::vector<uint8_t> too_big(nb, 0);
+  parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
+    std::vector<uint32_t> sh;
+    for (size_t b = b0; b < b1; ++b) {
+      std::vector<uint32_t> &u = bl_nodes[b];
+      sh.clear();
+      size_t ne = 0;
+      for (uint32_t node : u) { if (shared[node]) sh.push_back(node); else u[ne++] = node; }
+      std::copy(sh.begin(), sh.end(), u.begin() + ne);
+      if ((int)u.size() > bc * NV / 2) too_big[b] = 1;
+      blk_hdr[b * 4 + 0] = (uint32_t)u.size();
+      blk_hdr[b * 4 + 1] = (uint32_t)ne;
+    }
+  });
+  size_t nslots = 0;
   int max_u = 0;
   for (int b = 0; b < nb; ++b) {
-    const int U = (int)bl_sorted[b].size();
-    if (U > bc * NV / 2) return 0;  // (degenerate meshes) kernel's per-thread metadata bound: keep the slot path
-    max_u = std::max(max_u, U);
+    if (too_big[b]) return 0;  // (degenerate meshes) kernel's per-thread metadata bound: keep the slot path
+    max_u = std::max(max_u, (int)blk_hdr[(size_t)b * 4]);
+    blk_hdr[(size_t)b * 4 + 2] = (uint32_t)nslots;
+    nslots += blk_hdr[(size_t)b * 4] - blk_hdr[(size_t)b * 4 + 1];
   }
-  // pass 2: order of a block's nodes = exclusive nodes first, then the shared ones; inside either group by
-  // valence class (<= 2, <= 4, <= 8 slots: the node sums of the kernel read 2, 4 or 8 entries), then
-  // ascending.  Header {U | b2s << 16, nex | b4s << 16, first shared slot, b2e | b4e << 16}: b2x / b4x =
-  // local id of the first node of the group with more than 2 / 4 slots.  Then the node words, the local
-  // ids of the cells' nodes and up to 8 LDS slots per node in (cell, local dof) order.
+  // per block: node words, local ids of the cells' nodes, up to 8 LDS slots per node in (cell, local dof) order
   const int wtile = blk_wave_tile(dim);
   const uint16_t zero_slot = (uint16_t)(WAVES_PER_BLOCK * wtile);  // entries are LDS slot indices (doubles)
-  std::vector<uint32_t> blk_hdr((size_t)nb * 4, 0);
   std::vector<uint32_t> unodes((size_t)nb * max_u, 0);
   std::vector<uint16_t> uent8((size_t)nb * max_u * 8, zero_slot), lidT((size_t)LID_ROW * lv.cstride, 0);
   std::vector<uint8_t> valence_ok(nb, 1);
   parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
     std::vector<uint8_t> cnt;
-    std::vector<uint16_t> lid_of;        // sorted position -> local id
-    std::vector<uint32_t> order;
     for (size_t b = b0; b < b1; ++b) {
       const size_t c0 = b * bc, c1 = std::min(c0 + (size_t)bc, (size_t)lv.n_cells);
       const size_t m0 = b * max_u;
-      const std::vector<uint32_t> &u = bl_sorted[b];
-      const std::vector<uint8_t> &val = bl_val[b];
-      const int U = (int)u.size();
-      auto group = [&](int k) { return (shared[u[k]] ? 3 : 0) + (val[k] <= 2 ? 0 : (val[k] <= 4 ? 1 : 2)); };
-      int n_in[6] = {0, 0, 0, 0, 0, 0};
-      for (int k = 0; k < U; ++k) { if (val[k] > 8) valence_ok[b] = 0; ++n_in[group(k)]; }
-      int first[6];
-      first[0] = 0;
-      for (int g = 1; g < 6; ++g) first[g] = first[g - 1] + n_in[g - 1];
-      const int nex = first[3];
-      blk_hdr[b * 4 + 0] = (uint32_t)U | ((uint32_t)first[4] << 16);
-      blk_hdr[b * 4 + 1] = (uint32_t)nex | ((uint32_t)first[5] << 16);
-      blk_hdr[b * 4 + 3] = (uint32_t)first[1] | ((uint32_t)first[2] << 16);
-      lid_of.resize(U);
-      int fill[6];
-      for (int g = 0; g < 6; ++g) fill[g] = first[g];
-      for (int k = 0; k < U; ++k) {          // (u is ascending: so is every group)
-        const int l = fill[group(k)]++;
-        lid_of[k] = (uint16_t)l;
-        unodes[m0 + l] = u[k] | ((uint32_t)cmv[u[k]] << 29);
-      }
+      const std::vector<uint32_t> &u = bl_nodes[b];
+      const int U = (int)u.size(), ne = (int)blk_hdr[b * 4 + 1];
+      for (int l = 0; l < U; ++l) unodes[m0 + l] = u[l] | ((uint32_t)cmv[u[l]] << 29);
       cnt.assign(U, 0);
       for (size_t cell = c0; cell < c1; ++cell) {
         const int w = (int)(cell - c0) / cpw, jj = (int)(cell - c0) % cpw;
         for (int a = 0; a < NV; ++a) {
           const uint32_t node = hl.cnv[cell * NV + a];
-          const int l = lid_of[std::lower_bound(u.begin(), u.end(), node) - u.begin()];
+          const auto first = shared[node] ? u.begin() + ne : u.begin(), last = shared[node] ? u.end() : u.begin() + ne;
+          const int l = (int)(std::lower_bound(first, last, node) - u.begin());
           lidT[cell * LID_ROW + a] = (uint16_t)l;
-          if (cnt[l] >= 8) continue;  // node of valence > 8 inside one block (flagged above)
+          if (cnt[l] >= 8) { valence_ok[b] = 0; continue; }  // node of valence > 8 inside one block
           uent8[(m0 + l) * 8 + cnt[l]++] = (uint16_t)(w * wtile + a * BLK_SLOT_ROW + jj * dim);
         }
       }
     }
   });
   for (int b = 0; b < nb; ++b) if (!valence_ok[b]) return 0;   // keep the slot path
-  std::vector<std::vector<uint32_t>>().swap(bl_sorted);
-  std::vector<std::vector<uint8_t>>().swap(bl_val);
   // slots of the shared nodes, block by block
-  size_t nslots = 0;
-  for (int b = 0; b < nb; ++b) {
-    blk_hdr[(size_t)b * 4 + 2] = (uint32_t)nslots;
-    nslots += (blk_hdr[(size_t)b * 4] & 0xFFFFu) - (blk_hdr[(size_t)b * 4 + 1] & 0xFFFFu);
-  }
   std::vector<uint32_t> sh_count(nn, 0);
   std::vector<std::pair<uint32_t, uint32_t>> sh_pairs;  // (node, slot position)
   sh_pairs.reserve(nslots + send_nodes.size());
   for (int b = 0; b < nb; ++b) {
+    const std::vector<uint32_t> &u = bl_nodes[b];
     size_t slot = blk_hdr[(size_t)b * 4 + 2];
-    const uint32_t U = blk_hdr[(size_t)b * 4] & 0xFFFFu, nex = blk_hdr[(size_t)b * 4 + 1] & 0xFFFFu;
-    for (uint32_t l = nex; l < U; ++l) {
-      const uint32_t node = unodes[(size_t)b * max_u + l] & NODE_MASK;
-      sh_pairs.emplace_back(node, (uint32_t)slot++);
-      ++sh_count[node];
+    for (size_t l = blk_hdr[(size_t)b * 4 + 1]; l < u.size(); ++l) {
+      sh_pairs.emplace_back(u[l], (uint32_t)slot++);
+      ++sh_count[u[l]];
     }
   }
+  std::vector<std::vector<uint32_t>>().swap(bl_nodes);
   // remote partial sums: entry k of the receive buffer belongs to owned node send_nodes[k]
   for (size_t k = 0; k < send_nodes.size(); ++k) {
     sh_pairs.emplace_back(send_nodes[k], (uint32_t)(nslots + k));
@@ -529,7 +506,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
     std::vector<uint32_t> order, iface;
     for (int b = 0; b < nb; ++b) {
       bool ghost = false;
-      const int U = (int)(blk_hdr[(size_t)b * 4] & 0xFFFFu);
+      const int U = (int)blk_hdr[(size_t)b * 4];
       for (int l = 0; l < U && !ghost; ++l) ghost = (int)(unodes[(size_t)b * max_u + l] & NODE_MASK) >= lv.n_owned_v;
       (ghost ? iface : order).push_back((uint32_t)b);
     }

@@ -83,8 +83,7 @@ struct BlockTables {
   bool built = false;
   int block_cells = 0, n_blocks = 0, max_unodes = 0, n_shared = 0;
   size_t n_shared_slots = 0;
-  uint32_t *blk_hdr = nullptr;    // [n_blocks][4]: unique nodes | b2s << 16, exclusive nodes (they come first) | b4s << 16,
-                                  // first shared slot, b2e | b4e << 16 (valence-class boundaries, agmg.cpp build_block_tables)
+  uint32_t *blk_hdr = nullptr;    // [n_blocks][4]: unique nodes, exclusive nodes (they come first), first shared slot, 0
   uint32_t *unodes = nullptr;     // [n_blocks][max_unodes] global node | cmask << 29 of (block, local id)
   uint16_t *uent8 = nullptr;      // [n_blocks][max_unodes][8] LDS slot indices, padded with the zero slot
   uint16_t *lidT = nullptr;       // [cstride][LID_ROW] local id (within its block) of each cell node: one 64-byte

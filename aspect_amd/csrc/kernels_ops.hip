@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) k_pull(const PullArgs P) { pull_body<NC, 
 #endif
 struct BlkArgs {
   unsigned long long *dbg;
-  const uint4 *blk_hdr;      // per block {unique nodes | b2s << 16, exclusive nodes | b4s << 16, first shared slot, b2e | b4e << 16}
+  const uint4 *blk_hdr;      // per block {unique nodes, exclusive nodes, first shared slot, 0}
   const uint32_t *unodes;    // [n_blocks][max_u]: node | cmask << 29
   const uint4 *uent8;        // [n_blocks][max_u]: 8 LDS slot indices (16 bit each) per local node
   const uint16_t *lidT;      // [cstride][LID_ROW]: local id (within its block) of each cell node
@@ -479,35 +479,29 @@ template <int DIM> struct BlkLds {
 // node-owner sums of the block kernel, specialised on the epilogue (EPI) so the item loop has no
 // switch: one thread per node of the block and all DIM components; the 8 slot entries of a node
 // are LDS slot indices in doubles (missing ones point at the zero triple)
-struct BlkClasses { int b2e, b4e, b2s, b4s; };   // local ids of the first node with more than 2 / 4 slots (exclusive, shared)
 template <int DIM, int EPI>
 __device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *l_ent, const uint32_t *nd /* [MAXU_PT] */,
-                                              const int U, const int nex, const BlkClasses cls, const EpiArgs &E, double *slots_sh,
+                                              const int U, const int nex, const EpiArgs &E, double *slots_sh,
                                               const size_t sbase) {
   constexpr int NT = 64 * WAVES_PER_BLOCK;
   constexpr int MAXU_PT = (KDims<DIM>::CPW * WAVES_PER_BLOCK * KDims<DIM>::NV / 2 + NT - 1) / NT;
-  // (thread t finishes the nodes t, t + NT, ...: their words are the ones it holds in registers).  The nodes of
-  // either group (exclusive, shared) are ordered by the number of slots that hit them: 2, 4 or 8 entries are read
+  // (thread t finishes the nodes t, t + NT, ...: their words are the ones it holds in registers)
   uint4 e4[MAXU_PT];
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) e4[i] = l_ent[min((int)threadIdx.x + i * NT, U - 1)];
   double sum[MAXU_PT][DIM];
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) {
-    const int lid = min((int)threadIdx.x + i * NT, U - 1);
     const uint32_t ew[4] = {e4[i].x, e4[i].y, e4[i].z, e4[i].w};
-    const bool more2 = lid >= (lid < nex ? cls.b2e : cls.b2s), more4 = lid >= (lid < nex ? cls.b4e : cls.b4s);
 #pragma unroll
     for (int cc = 0; cc < DIM; ++cc) sum[i][cc] = 0.0;
-    auto add = [&](const int k) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
       const uint32_t off = (k & 1) ? (ew[k >> 1] >> 16) : (ew[k >> 1] & 0xFFFFu);
       const double *p = reinterpret_cast<const double *>(slots_c) + off;
 #pragma unroll
       for (int cc = 0; cc < DIM; ++cc) sum[i][cc] += p[cc];
-    };
-    add(0); add(1);
-    if (more2) { add(2); add(3); }
-    if (more4) { add(4); add(5); add(6); add(7); }
+    }
   }
 #pragma unroll
   for (int i = 0; i < MAXU_PT; ++i) {
@@ -599,7 +593,7 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
                                        (__attribute__((address_space(3))) void *)(l_ent + i * NT + wave * 64), 16, 0, 0);
   }
   const uint4 hdr = B.blk_hdr[blk];
-  const int U = (int)(hdr.x & 0xFFFFu), nex = (int)(hdr.y & 0xFFFFu);
+  const int U = (int)hdr.x, nex = (int)hdr.y;
   uint32_t lids[HAS_U ? NV : 1];
   if (HAS_U) {
 #pragma unroll
@@ -695,10 +689,9 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   if (slots[threadIdx.x] != 12345.678) return;
 #endif
   const size_t sbase = (size_t)hdr.z * DIM;
-  const BlkClasses cls{(int)(hdr.w & 0xFFFFu), (int)(hdr.w >> 16), (int)(hdr.x >> 16), (int)(hdr.y >> 16)};
-  if (E.epi == EPI_CHEB) blk_node_sums<DIM, EPI_CHEB>(smem_c, l_ent, m_node, U, nex, cls, E, B.slots_sh, sbase);
-  else if (E.epi == EPI_RESID) blk_node_sums<DIM, EPI_RESID>(smem_c, l_ent, m_node, U, nex, cls, E, B.slots_sh, sbase);
-  else blk_node_sums<DIM, EPI_STORE>(smem_c, l_ent, m_node, U, nex, cls, E, B.slots_sh, sbase);
+  if (E.epi == EPI_CHEB) blk_node_sums<DIM, EPI_CHEB>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
+  else if (E.epi == EPI_RESID) blk_node_sums<DIM, EPI_RESID>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
+  else blk_node_sums<DIM, EPI_STORE>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
   AGMG_STAMP(5);
 }
 
