@@ -412,6 +412,37 @@ def viscosity_tables(hier, eta_func, averaging):
 # ---------------------------------------------------------------------------
 # Right-hand side  f_u = int rho g . phi_u  (assemblers/stokes.cc:433-442)
 # ---------------------------------------------------------------------------
+def assemble_boundary_traction(level, boundary_id, traction):
+    """int_Gamma phi_i . t dS over the faces of one box boundary (Gauss-3 per tangential direction), as a
+    velocity vector [node][component]; constrained rows are zeroed like the rest of the right-hand side."""
+    dim = level.dim
+    cells, fnos = level.boundary_faces(boundary_id)
+    rhs = np.zeros((level.n_nodes_v, dim))
+    if len(cells) == 0:
+        return rhs.reshape(-1)
+    x, normal, jxw = level.face_geometry(cells, fnos)
+    nqf = 3 ** (dim - 1)
+    qt = np.indices((3,) * (dim - 1)).reshape(dim - 1, -1)[::-1]
+    loc = np.indices((3,) * dim).reshape(dim, -1)[::-1]
+    t = traction(x.reshape(-1, dim)).reshape(x.shape)
+    for fno in np.unique(fnos):
+        sel = np.nonzero(fnos == fno)[0]
+        d, side = int(fno) // 2, int(fno) % 2
+        tang = [k for k in range(dim) if k != d]
+        xi = np.zeros((nqf, dim))
+        xi[:, d] = float(side)
+        for m, k in enumerate(tang):
+            xi[:, k] = GAUSS3_X[qt[m]]
+        N = np.ones((nqf, 3 ** dim))
+        for k in range(dim):
+            N *= q2_shape(xi[:, k])[:, loc[k]]
+        contrib = np.einsum("qi,fq,fqd->fid", N, jxw[sel], t[sel])          # [face][local node][component]
+        np.add.at(rhs, level.cell_nodes_v[cells[sel]].astype(np.int64), contrib)
+    bits = ((level.cmask_v[:, None] >> np.arange(dim)[None, :]) & 1).astype(bool)
+    rhs[bits] = 0.0
+    return rhs.reshape(-1)
+
+
 def assemble_rhs_u(level, force_func, force_q=None):
     """force_func(x[n,dim]) -> rho*g [n,dim], or force_q(level) -> rho*g at the q-points
     [n_cells,nq,dim]; constrained rows are zeroed."""

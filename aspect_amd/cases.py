@@ -70,6 +70,9 @@ class StokesProblem:
     make_hierarchy: callable = None     # (refinement, only_finest) -> hierarchy (other geometries than the box)
     boundary_velocity: callable = None  # x -> prescribed velocity on the constrained nodes (inhomogeneous Dirichlet)
     pressure_scaling_from_mesh: callable = None   # finest level -> lambda (helper_functions.cc:252-350)
+    # prescribed boundary tractions {box boundary id: x -> traction vector [n, dim]}: rhs_u += int_Gamma phi . t dS
+    # (source/simulator/assemblers/stokes.cc, StokesBoundaryTraction)
+    boundary_traction: dict = None
 
     def _hierarchy(self, only_finest):
         if self.make_hierarchy is not None:
@@ -85,6 +88,8 @@ class StokesProblem:
             bm.viscosity_tables(self.hier, self.eta, self.averaging)
         fin = self.hier.finest
         self.rhs_u = bm.assemble_rhs_u(fin, self.force, self.force_q)
+        for b, traction in (self.boundary_traction or {}).items():
+            self.rhs_u += bm.assemble_boundary_traction(fin, b, traction)
         self.rhs_p = np.zeros(fin.n_dofs_p)
         if self.initial_pressure is not None:
             self.p0 = self.initial_pressure(fin.node_coords_p()) / self.pressure_scaling
@@ -359,6 +364,25 @@ def periodic_box_2d(refinement=5, no_slip_walls=False):
         eta=lambda x: np.full(x.shape[0], 1e20), force=None, force_q=force_q,
         averaging=bm.AVG_HARMONIC, pressure_scaling=1e20 / (0.01 * X), extents=[X, Y],
         periodic=[True, False], tol=1e-8, n_cheap=100, n_expensive=1000, initial_pressure=p_static)
+
+
+def poiseuille_2d(refinement=4):
+    """tests/poiseuille_2d_pressure_bc_gmg.prm: box 2 x 1 (one coarse cell), eta = 1, no gravity, no slip on top and
+    bottom, the traction (2, 0) prescribed on the open left and right boundaries (pressure 2 at the inlet, -2 at the
+    outlet); harmonic averaging, tolerance 1e-6, 200 cheap steps, restart 100."""
+    X, Y = 2.0, 1.0
+
+    def traction(x):
+        t = np.zeros_like(x)
+        t[:, 0] = 2.0
+        return t
+
+    return StokesProblem(
+        name=f"poiseuille_2d_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_NONE, bm.BC_NONE, bm.BC_ZERO, bm.BC_ZERO],
+        eta=lambda x: np.ones(x.shape[0]), force=lambda x: np.zeros_like(x),
+        averaging=bm.AVG_HARMONIC, pressure_scaling=1.0 / (0.01 * X), extents=[X, Y],
+        tol=1e-6, restart=100, n_cheap=200, n_expensive=0, boundary_traction={0: traction, 1: traction})
 
 
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))

@@ -78,6 +78,52 @@ def rms_max_velocity(p, x):
     return np.sqrt((m2 * W[None, :]).sum() / vol), np.sqrt(m2.max())
 
 
+def boundary_mass_flux(p, x, boundary_id, density=1.0):
+    """'Mass fluxes through boundary parts' of postprocess/mass_flux_statistics.cc: int_Gamma rho u . n dS over
+    one box boundary (Gauss-3 per tangential direction)."""
+    fin = p.hier.finest
+    dim = fin.dim
+    u = x[:fin.n_dofs_v].reshape(-1, dim)
+    cells, fnos = fin.boundary_faces(boundary_id)
+    xq, normal, jxw = fin.face_geometry(cells, fnos)
+    nqf = 3 ** (dim - 1)
+    qt = np.indices((3,) * (dim - 1)).reshape(dim - 1, -1)[::-1]
+    loc = np.indices((3,) * dim).reshape(dim, -1)[::-1]
+    flux = 0.0
+    for fno in np.unique(fnos):
+        sel = np.nonzero(fnos == fno)[0]
+        d, side = int(fno) // 2, int(fno) % 2
+        xi = np.zeros((nqf, dim))
+        xi[:, d] = float(side)
+        for m, k in enumerate([k for k in range(dim) if k != d]):
+            xi[:, k] = bm.GAUSS3_X[qt[m]]
+        N = np.ones((nqf, 3 ** dim))
+        for k in range(dim):
+            N *= bm.q2_shape(xi[:, k])[:, loc[k]]
+        uq = np.einsum("qi,fid->fqd", N, u[fin.cell_nodes_v[cells[sel]].astype(np.int64)])
+        flux += density * np.einsum("fqd,fqd,fq->", uq, normal[sel], jxw[sel])
+    return flux
+
+
+def poiseuille_checks(p, x, rep, gold):
+    """tests/poiseuille_2d_pressure_bc_gmg/screen-output: iteration counts of the solver and of both V-cycle
+    preconditioners, RMS / max velocity, pressure range and the mass fluxes through the open boundaries, to the
+    digits the reference prints."""
+    so = gold["solves"][0]
+    fin = p.hier.finest
+    assert rep.n_cheap_iterations == so["cheap"] and rep.n_expensive_iterations == so["expensive"]
+    assert rep.n_A_preconditioner_cheap == so["A_cheap"] and rep.n_S_preconditioner_cheap == so["S_cheap"]
+    rms, vmax = rms_max_velocity(p, x)
+    g_rms, g_max = gold["rms_max_velocity"][0]
+    assert abs(rms - g_rms) < 5.1e-4 and abs(vmax - g_max) < 5.1e-3, (rms, vmax)          # 0.193, 0.27
+    pr = x[fin.n_dofs_v:] * p.pressure_scaling
+    pmin, pavg, pmax = gold["pressure_min_avg_max"][0]
+    assert abs(pr.min() - pmin) < 5.1e-4 and abs(pr.max() - pmax) < 5.1e-4, (pr.min(), pr.max())   # -2.413, 2.413
+    fl = gold["mass_fluxes"][0]
+    for b in range(4):
+        assert abs(boundary_mass_flux(p, x, b) - fl[b]) < 5.1e-5, (b, boundary_mass_flux(p, x, b), fl[b])   # -0.1752, 0.1752, 0, 0
+
+
 def relative_residual_second_iteration(solver, p, x1, rep1):
     """'Relative nonlinear residual (Stokes system) after nonlinear iteration 2' of the iterated Stokes
     scheme (solver_schemes.cc:507-527, 910-915): the residual the second solve() finds for the first

@@ -697,6 +697,17 @@ def test_stokes_golden_iterations_and_velocities(hip_lib):
     assert rc == 0 and abs(vmax / g_max - 1.0) < 0.15 and 1.0 / 6.0 < rms / g_rms < 6.0, (rms, vmax)
 
 
+def test_poiseuille_pressure_boundary_golden(hip_lib):
+    """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
+    reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""
+    p = cases.poiseuille_2d(4).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0
+    sc.poiseuille_checks(p, x, rep, GOLD["poiseuille_2d_pressure_bc_gmg"])
+
+
 @pytest.mark.parametrize("case", ["nsinker_r3_harmonic", "box3d_r2_freeslip", "deformed3d_r2_harmonic", "solcx_r2",
                                   "free_surface_2d", "free_surface_3d_deformed"])
 def test_rhs_correction(case, hip_lib, oracle_lib):

@@ -399,6 +399,25 @@ def test_stokes_rms_and_max_velocity():
     assert 1.0 / 6.0 < rms / g_rms < 6.0, (rms, g_rms)
 
 
+def test_poiseuille_pressure_boundary_golden():
+    """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
+    right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
+    14+0 iterations with 15 V-cycles of either block, RMS / max velocity 0.193 / 0.27, pressure -2.413 .. 2.413,
+    mass fluxes -0.1752 / 0.1752 / 0 / 0: all reproduced to the digits printed."""
+    g = G["poiseuille_2d_pressure_bc_gmg"]
+    p = cases.poiseuille_2d(4).build()
+    fin, m, so = p.hier.finest, g["meshes"][0], g["solves"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"] == so["n_levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    assert p.hier.levels[0].n_dofs_v == so["coarse_A"] and p.hier.levels[0].n_dofs_p == so["coarse_S"]
+    assert p.eta_min == so["eta_min"] and p.eta_max == so["eta_max"]
+    s = pyoracle.solver(p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0
+    sc.poiseuille_checks(p, x, rep, g)
+
+
 def test_rhs_correction_equals_unconstrained_operator():
     """correct_stokes_rhs (local_smoothing.cc:761-898): rhs += -M u0 with u0 read without the
     constraints and constrained rows dropped.  Parity unpinned by a reference number here (its golden,
