@@ -412,6 +412,21 @@ def viscosity_tables(hier, eta_func, averaging):
 # ---------------------------------------------------------------------------
 # Right-hand side  f_u = int rho g . phi_u  (assemblers/stokes.cc:433-442)
 # ---------------------------------------------------------------------------
+def assemble_rhs_p(level, func):
+    """int func(x) phi_p dx at the pressure nodes (Gauss-3 per direction)."""
+    dim = level.dim
+    f = func(level.qpoint_coords().reshape(-1, dim)).reshape(level.n_cells, -1)
+    Nq = tensor_shape([N1] * dim)                      # [q][i]
+    if level.general:
+        loc = np.einsum("qi,cq,cq->ci", Nq, level.jxw, f)
+    else:
+        W = tensor_shape([GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(level.h)
+        loc = np.einsum("qi,q,cq->ci", Nq, W, f)
+    out = np.zeros(level.n_nodes_p)
+    np.add.at(out, level.cell_nodes_p.astype(np.int64), loc)
+    return out
+
+
 def assemble_boundary_traction(level, boundary_id, traction):
     """int_Gamma phi_i . t dS over the faces of one box boundary (Gauss-3 per tangential direction), as a
     velocity vector [node][component]; constrained rows are zeroed like the rest of the right-hand side."""

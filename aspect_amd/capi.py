@@ -229,7 +229,7 @@ class Solver:
         self._check(lib.set_level(self.ctx, ACTIVE, None))
         for l, lev in enumerate(hier.levels):
             self._set_coeff(l, problem.eta_levels[l])
-        self._set_coeff(ACTIVE, problem.eta_active)
+        self._set_coeff(ACTIVE, problem.eta_active, dilation=getattr(problem, "dilation", None))
         if getattr(problem, "free_surface", None) is not None:
             self.set_free_surface_faces(*problem.free_surface)
         if not single_level:

@@ -73,6 +73,11 @@ class StokesProblem:
     # prescribed boundary tractions {box boundary id: x -> traction vector [n, dim]}: rhs_u += int_Gamma phi . t dS
     # (source/simulator/assemblers/stokes.cc, StokesBoundaryTraction)
     boundary_traction: dict = None
+    # prescribed dilation (Formulation: Enable prescribed dilation; assemblers/stokes.cc:453-480): div u = R enters
+    # the pressure rows of the right-hand side as -lambda int R phi_p, the operator of the active mesh becomes
+    # deviatoric and carries -lambda^2 int L p q in its pressure block.  dilation_rhs / dilation_lhs: x -> R, L
+    dilation_rhs: callable = None
+    dilation_lhs: callable = None
 
     def _hierarchy(self, only_finest):
         if self.make_hierarchy is not None:
@@ -91,6 +96,12 @@ class StokesProblem:
         for b, traction in (self.boundary_traction or {}).items():
             self.rhs_u += bm.assemble_boundary_traction(fin, b, traction)
         self.rhs_p = np.zeros(fin.n_dofs_p)
+        self.dilation = None
+        if self.dilation_rhs is not None:
+            self.rhs_p = -self.pressure_scaling * bm.assemble_rhs_p(fin, self.dilation_rhs)
+            xq = fin.qpoint_coords().reshape(-1, self.dim)
+            lhs = np.zeros(xq.shape[0]) if self.dilation_lhs is None else self.dilation_lhs(xq)
+            self.dilation = (np.ascontiguousarray(lhs.reshape(fin.n_cells, -1)), None, None)
         if self.initial_pressure is not None:
             self.p0 = self.initial_pressure(fin.node_coords_p()) / self.pressure_scaling
         else:
@@ -364,6 +375,29 @@ def periodic_box_2d(refinement=5, no_slip_walls=False):
         eta=lambda x: np.full(x.shape[0], 1e20), force=None, force_q=force_q,
         averaging=bm.AVG_HARMONIC, pressure_scaling=1e20 / (0.01 * X), extents=[X, Y],
         periodic=[True, False], tol=1e-8, n_cheap=100, n_expensive=1000, initial_pressure=p_static)
+
+
+def prescribed_dilation_2d(refinement=3, eta=10.0):
+    """tests/prescribed_dilation_gmg.prm (+ prescribed_dilation.prm / .cc): manufactured solution u = (cos y,
+    sin x + x y), p = -2/3 eta (x - 1) on [0, 2]^2 with div u = x prescribed as dilation, the body force
+    (-eta (1 - cos y), eta sin x) as additional Stokes right-hand side, the analytic velocity on all four
+    boundaries; eta = 10, harmonic averaging, tolerance 1e-12, 200 cheap steps."""
+    X = 2.0
+
+    def force(x):
+        return np.stack([-eta * (1.0 - np.cos(x[:, 1])), eta * np.sin(x[:, 0])], axis=1)
+
+    def velocity(x):
+        return np.stack([np.cos(x[:, 1]), np.sin(x[:, 0]) + x[:, 0] * x[:, 1]], axis=1)
+
+    pr = StokesProblem(
+        name=f"prescribed_dilation_2d_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_ZERO] * 4,
+        eta=lambda x: np.full(x.shape[0], eta), force=force, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=eta / (0.01 * X), extents=[X, X], tol=1e-12, restart=100, n_cheap=200, n_expensive=1000,
+        boundary_velocity=velocity, dilation_rhs=lambda x: x[:, 0])
+    pr.analytic_velocity = velocity
+    pr.analytic_pressure = lambda x: -2.0 / 3.0 * eta * (x[:, 0] - 1.0)
+    return pr
 
 
 def poiseuille_2d(refinement=4):

@@ -12,7 +12,7 @@ REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", "nsinker_gmg_idr",
          "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
          "particle_interpolator_bilinear_3d", "periodic_box_gmg", "nsinker_gmg_gc",
-         "poiseuille_2d_pressure_bc_gmg"]
+         "poiseuille_2d_pressure_bc_gmg", "prescribed_dilation_gmg"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 
@@ -65,6 +65,9 @@ def parse(path):
         m = re.search(r"Mass fluxes through boundary parts:\s+(.*)$", line)
         if m:
             out.setdefault("mass_fluxes", []).append([float(t.split()[0]) for t in m.group(1).split(",")])
+        m = re.search(r"Errors u_L2, p_L2:\s+([^,\s]+),\s*([^,\s]+)", line)
+        if m:
+            out.setdefault("errors_uL2_pL2", []).append([float(m.group(1)), float(m.group(2))])
         m = re.search(r"Errors u_L1, p_L1, u_L2, p_L2(?: topo_L2)?:?\s+([^,\s]+),\s*([^,\s]+),\s*([^,\s]+),\s*([^,\s]+)", line)
         if m:
             out["errors_uL1_pL1_uL2_pL2"] = [float(m.group(i)) for i in range(1, 5)]

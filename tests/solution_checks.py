@@ -65,17 +65,86 @@ def solcx_errors(p, x):
 
 
 def rms_max_velocity(p, x):
-    """'RMS, max velocity' of postprocess/velocity_statistics.cc: sqrt(int |u|^2 / volume) and the
-    largest |u| over the quadrature points, Gauss-3 per direction (quadrature_formulas.velocities)."""
+    """'RMS, max velocity' of postprocess/velocity_statistics.cc:38-41: sqrt(int |u|^2 / volume) and the largest
+    |u| over the points of a Gauss-Lobatto rule with velocity degree + 2 = 4 points per direction (it includes the
+    cell vertices, so the maximum sees the boundary values)."""
     fin = p.hier.finest
     dim = fin.dim
     u = x[:fin.n_dofs_v].reshape(-1, dim)
-    S = bm.tensor_shape([bm.N2] * dim)
-    W = bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(fin.h)
+    a = 0.5 / np.sqrt(5.0)
+    gx = np.array([0.0, 0.5 - a, 0.5 + a, 1.0])
+    gw = np.array([1.0, 5.0, 5.0, 1.0]) / 12.0
+    S = bm.tensor_shape([bm.q2_shape(gx)] * dim)
     uq = np.einsum("qi,cid->cqd", S, u[fin.cell_nodes_v.astype(np.int64)])
     m2 = (uq ** 2).sum(axis=2)
+    if getattr(fin, "general", False):
+        # (general geometry: the level's own Gauss-3 JxW; only boxes carry goldens of this quantity)
+        S3 = bm.tensor_shape([bm.N2] * dim)
+        u3 = np.einsum("qi,cid->cqd", S3, u[fin.cell_nodes_v.astype(np.int64)])
+        return np.sqrt((((u3 ** 2).sum(axis=2)) * fin.jxw).sum() / fin.jxw.sum()), np.sqrt(m2.max())
+    W = bm.tensor_shape([gw.reshape(-1, 1)] * dim).reshape(-1) * np.prod(fin.h)
     vol = np.prod(fin.extents)
     return np.sqrt((m2 * W[None, :]).sum() / vol), np.sqrt(m2.max())
+
+
+def analytic_l2_errors(p, x):
+    """u_L2 and p_L2 against p.analytic_velocity / p.analytic_pressure as tests/prescribed_dilation.cc computes them:
+    VectorTools::integrate_difference with QGauss(velocity degree + 2) = 4 points per direction, cell-wise errors stored
+    as float, pressure normalised to zero volume average (Pressure normalization = volume)."""
+    fin = p.hier.finest
+    dim = fin.dim
+    gx, gw = _gauss(4)
+    S2 = bm.tensor_shape([bm.q2_shape(gx)] * dim)
+    S1 = bm.tensor_shape([bm.q1_shape(gx)] * dim)
+    W = bm.tensor_shape([gw.reshape(-1, 1)] * dim).reshape(-1) * np.prod(fin.h)
+    u = x[:fin.n_dofs_v].reshape(-1, dim)
+    pr = x[fin.n_dofs_v:] * p.pressure_scaling
+    X = fin.node_coords_v()
+    xq = np.einsum("qi,cid->cqd", S2, X[fin.cell_nodes_v.astype(np.int64)])
+    uq = np.einsum("qi,cid->cqd", S2, u[fin.cell_nodes_v.astype(np.int64)])
+    pq = np.einsum("qi,ci->cq", S1, pr[fin.cell_nodes_p.astype(np.int64)])
+    pq = pq - (pq * W[None, :]).sum() / (W.sum() * fin.n_cells)
+    ue = p.analytic_velocity(xq.reshape(-1, dim)).reshape(uq.shape)
+    pe = p.analytic_pressure(xq.reshape(-1, dim)).reshape(pq.shape)
+    eu = np.sqrt((((uq - ue) ** 2).sum(axis=2) * W[None, :]).sum(axis=1)).astype(np.float32).astype(np.float64)
+    ep = np.sqrt(((pq - pe) ** 2 * W[None, :]).sum(axis=1)).astype(np.float32).astype(np.float64)
+    return np.sqrt((eu ** 2).sum()), np.sqrt((ep ** 2).sum())
+
+
+def solve_prescribed_dilation(solver_factory, refinement):
+    """The iterated-Stokes sequence of tests/prescribed_dilation_gmg on one mesh: correct_stokes_rhs, first solve,
+    second solve from the first solution."""
+    from aspect_amd import cases
+    p = cases.prescribed_dilation_2d(refinement).build()
+    s = solver_factory(p)
+    rhs = s.rhs_correction(p.u0, np.concatenate([p.rhs_u, p.rhs_p]))
+    x, rep, rc = s.solve(rhs=rhs)
+    x2, rep2, rc2 = s.solve(rhs=rhs, x0=x)
+    s.close()
+    nu = p.hier.finest.n_dofs_v
+    x = x.copy()
+    x[:nu] += p.u0[:nu]                                   # constraints.distribute(): the boundary values
+    return p, x, rep, rc, rep2, rhs
+
+
+def check_prescribed_dilation(gold, mesh, p, x, rep, rc, rep2, rhs):
+    """tests/prescribed_dilation_gmg/screen-output, mesh 0 (64 cells) or 1 (256 cells): DoF counts, iteration counts of both
+    nonlinear iterations, the relative nonlinear residual of the second one, RMS / max velocity and the L2 errors against the
+    manufactured solution to the digits printed (the errors: 7 digits)."""
+    fin, m = p.hier.finest, gold["meshes"][mesh]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    s1, s2 = gold["solves"][2 * mesh], gold["solves"][2 * mesh + 1]
+    assert rc == 0 and rep.n_cheap_iterations == s1["cheap"] and rep.n_expensive_iterations == s1["expensive"]
+    assert rep2.n_cheap_iterations == s2["cheap"] and rep2.n_expensive_iterations == s2["expensive"]
+    rel2 = rep2.initial_nonlinear_residual / np.linalg.norm(rhs)
+    assert abs(rel2 / gold["nonlinear_residuals"][2 * mesh + 1] - 1.0) < 0.05, rel2
+    rms, vmax = rms_max_velocity(p, x)
+    g_rms, g_max = gold["rms_max_velocity"][mesh]
+    assert abs(rms - g_rms) < 5.1e-3 and abs(vmax - g_max) < 5.1e-3, (rms, vmax)
+    eu, ep = analytic_l2_errors(p, x)
+    gu, gp = gold["errors_uL2_pL2"][mesh]
+    assert abs(eu / gu - 1.0) < 2e-6 and abs(ep / gp - 1.0) < 2e-6, (eu, ep, gu, gp)
 
 
 def boundary_mass_flux(p, x, boundary_id, density=1.0):

@@ -697,6 +697,14 @@ def test_stokes_golden_iterations_and_velocities(hip_lib):
     assert rc == 0 and abs(vmax / g_max - 1.0) < 0.15 and 1.0 / 6.0 < rms / g_rms < 6.0, (rms, vmax)
 
 
+@pytest.mark.parametrize("mesh", [0, 1])
+def test_prescribed_dilation_golden(mesh, hip_lib):
+    """tests/prescribed_dilation_gmg: the HIP solve reproduces iteration counts, the second nonlinear residual, velocities
+    and the L2 errors against the manufactured solution in every printed digit (tests/test_oracle_goldens.py has the story)."""
+    sc.check_prescribed_dilation(GOLD["prescribed_dilation_gmg"], mesh,
+                                 *sc.solve_prescribed_dilation(lambda p: capi.Solver(hip_lib, p), 3 + mesh))
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -399,6 +399,16 @@ def test_stokes_rms_and_max_velocity():
     assert 1.0 / 6.0 < rms / g_rms < 6.0, (rms, g_rms)
 
 
+@pytest.mark.parametrize("mesh", [0, 1])
+def test_prescribed_dilation_golden(mesh):
+    """tests/prescribed_dilation_gmg (Formulation: prescribed dilation + additional Stokes right-hand side; manufactured
+    solution with div u = x, inhomogeneous Dirichlet values on all boundaries): 35+0 / 36+0 iterations, 0+0 in the second
+    nonlinear iteration, its relative residual 3.91178e-13 / 5.33873e-13, RMS / max velocity 2.13 / 4.93 and the L2 errors
+    1.794305e-04, 8.789932e-05 / 2.245432e-05, 5.910004e-06 in every printed digit.  Pins the deviatoric active operator with
+    the dilation terms (matrix_free_operators.cc:230-234, 259-268), the pressure right-hand side and correct_stokes_rhs."""
+    sc.check_prescribed_dilation(G["prescribed_dilation_gmg"], mesh, *sc.solve_prescribed_dilation(pyoracle.solver, 3 + mesh))
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
