@@ -321,6 +321,7 @@ class BoxHierarchy:
 AVG_NONE = "none"
 AVG_HARMONIC = "harmonic average only viscosity"
 AVG_PROJECT_Q1 = "project to Q1 only viscosity"
+AVG_GEOMETRIC = "geometric average only viscosity"
 
 
 def _dgq1_tables(dim):
@@ -365,10 +366,13 @@ def viscosity_tables(hier, eta_func, averaging):
     eta_min, eta_max = float(eta_q.min()), float(eta_q.max())
     nL = hier.n_levels
     ch = 1 << dim
-    if averaging == AVG_HARMONIC:
-        # unweighted harmonic mean N / sum(1/eta_q), interface.cc:542-561;
-        # min/max are taken AFTER averaging (local_smoothing.cc:247-275)
-        cellv = eta_q.shape[1] / np.sum(1.0 / eta_q, axis=1)
+    if averaging in (AVG_HARMONIC, AVG_GEOMETRIC):
+        # unweighted harmonic mean N / sum(1/eta_q), or geometric mean exp(sum(log eta_q) / N) (material_model/
+        # interface.cc, average_property); min/max are taken AFTER averaging (local_smoothing.cc:247-275)
+        if averaging == AVG_HARMONIC:
+            cellv = eta_q.shape[1] / np.sum(1.0 / eta_q, axis=1)
+        else:
+            cellv = np.exp(np.log(eta_q).mean(axis=1))
         eta_min, eta_max = float(cellv.min()), float(cellv.max())
         active = cellv[:, None].copy()
         levels = [None] * nL

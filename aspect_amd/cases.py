@@ -400,6 +400,59 @@ def prescribed_dilation_2d(refinement=3, eta=10.0):
     return pr
 
 
+def geometric_average_box(refinement=1):
+    """tests/geometric_average_only_viscosity.prm: box 100 x 100, T = 200 - x, `simple` material with
+    eta = 1e14 exp(-ln(1e4) (T - 100) / 100) (1e10 .. 1e14), rho = 3300 (1 - 2e-5 (T - 100)), g = 10, free slip on all
+    sides, geometric averaging of the viscosity per cell; default solver parameters (tolerance 1e-7, 200 cheap steps,
+    restart 100 since 3.1.0-pre); pressure scaling = exp(mean log eta at the cell midpoints) / (0.01 X)
+    (helper_functions.cc:252-350)."""
+    X = 100.0
+
+    def temperature(x):
+        return 200.0 - x[:, 0]
+
+    def eta(x):
+        return 1e14 * np.clip(np.exp(-9.210340372 * (temperature(x) - 100.0) / 100.0), 1e-6, 1e2)
+
+    def force(x):
+        f = np.zeros_like(x)
+        f[:, 1] = -10.0 * 3300.0 * (1.0 - 2e-5 * (temperature(x) - 100.0))
+        return f
+
+    def scaling(fin):
+        return float(np.exp(np.log(eta(fin.cell_centers())).mean())) / (0.01 * X)
+
+    return StokesProblem(
+        name=f"geometric_average_box_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_TANGENTIAL] * 4,
+        eta=eta, force=force, averaging=bm.AVG_GEOMETRIC, pressure_scaling=1.0, extents=[X, X],
+        tol=1e-7, restart=100, n_cheap=200, n_expensive=1000, pressure_scaling_from_mesh=scaling)
+
+
+def free_surface_blob_deck(refinement=3):
+    """tests/free_surface_blob_gmg.prm (+ free_surface_blob.prm), first Stokes solve (time step 0 on the first, uniform
+    mesh): box 500 km x 200 km of 5 x 2 coarse cells, eta = 1e21, a hot blob (T = 200 within 25 km of the centre, as
+    a Q2 field) with rho = 3300 (1 - 4e-5 T), g = 10; free slip left and right, no slip at the bottom, the top is the
+    free surface: open, and its stabilisation term vanishes with dt = 0.  No cheap steps: FGMRES with the inner CG
+    solves only; tolerance 1e-7."""
+    X, Y = 500.0e3, 200.0e3
+
+    def temperature_nodal(x):
+        return np.where(np.sqrt((x[:, 0] - 250e3) ** 2 + (x[:, 1] - 100e3) ** 2) < 25e3, 200.0, 0.0)
+
+    def force_q(level):
+        tq = level.nodal_to_qpoints(temperature_nodal(level.node_coords_v()))
+        f = np.zeros(tq.shape + (2,))
+        f[:, :, 1] = -10.0 * 3300.0 * (1.0 - 4e-5 * tq)
+        return f
+
+    return StokesProblem(
+        name=f"free_surface_blob_deck_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_TANGENTIAL, bm.BC_TANGENTIAL, bm.BC_ZERO, bm.BC_NONE],
+        eta=lambda x: np.full(x.shape[0], 1e21), force=None, force_q=force_q, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=1e21 / (0.01 * X), extents=[X, Y], reps=[5, 2], tol=1e-7, restart=100, n_cheap=0, n_expensive=1000,
+        initial_pressure=lambda x: 3300.0 * 10.0 * (Y - x[:, 1]))
+
+
 def poiseuille_2d(refinement=4):
     """tests/poiseuille_2d_pressure_bc_gmg.prm: box 2 x 1 (one coarse cell), eta = 1, no gravity, no slip on top and
     bottom, the traction (2, 0) prescribed on the open left and right boundaries (pressure 2 at the inlet, -2 at the

@@ -705,6 +705,26 @@ def test_prescribed_dilation_golden(mesh, hip_lib):
                                  *sc.solve_prescribed_dilation(lambda p: capi.Solver(hip_lib, p), 3 + mesh))
 
 
+def test_geometric_average_only_viscosity_golden(hip_lib):
+    """tests/geometric_average_only_viscosity: 8+0 iterations."""
+    p = cases.geometric_average_box(1).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0 and rep.n_cheap_iterations == GOLD["geometric_average_only_viscosity"]["solves"][0]["cheap"]
+    assert rep.n_expensive_iterations == 0
+
+
+def test_free_surface_blob_first_solve_golden(hip_lib):
+    """tests/free_surface_blob_gmg, first solve: 0+11 iterations (expensive solver only, open top boundary)."""
+    p = cases.free_surface_blob_deck(3).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    so = GOLD["free_surface_blob_gmg"]["solves"][0]
+    assert rc == 0 and rep.n_cheap_iterations == 0 and rep.n_expensive_iterations == so["expensive"]
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -409,6 +409,36 @@ def test_prescribed_dilation_golden(mesh):
     sc.check_prescribed_dilation(G["prescribed_dilation_gmg"], mesh, *sc.solve_prescribed_dilation(pyoracle.solver, 3 + mesh))
 
 
+def test_geometric_average_only_viscosity_golden():
+    """tests/geometric_average_only_viscosity: temperature-dependent viscosity 1e10 .. 1e14 averaged geometrically per
+    cell, 4 cells on 2 levels, 50+9 DoFs, 8+0 iterations (the only numbers its golden holds for the solve)."""
+    g = G["geometric_average_only_viscosity"]
+    p = cases.geometric_average_box(1).build()
+    fin, m = p.hier.finest, g["meshes"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    s = pyoracle.solver(p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0 and rep.n_cheap_iterations == g["solves"][0]["cheap"] and rep.n_expensive_iterations == 0
+
+
+def test_free_surface_blob_first_solve_golden():
+    """tests/free_surface_blob_gmg, first mesh and first solve (dt = 0: no stabilisation yet; the later solves need the
+    mesh-deformation time stepping): 640 cells on 4 levels from 5 x 2 coarse cells, 5,346+697 DoFs, no cheap steps:
+    0+11 iterations of FGMRES with the inner CG solves."""
+    g = G["free_surface_blob_gmg"]
+    p = cases.free_surface_blob_deck(3).build()
+    fin, m = p.hier.finest, g["meshes"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    s = pyoracle.solver(p)
+    x, rep, rc = s.solve()
+    s.close()
+    so = g["solves"][0]
+    assert rc == 0 and rep.n_cheap_iterations == so["cheap"] == 0 and rep.n_expensive_iterations == so["expensive"]
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
