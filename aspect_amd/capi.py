@@ -227,9 +227,10 @@ class Solver:
         for l, lev in enumerate(hier.levels):
             self._set_level(l, lev)
         self._check(lib.set_level(self.ctx, ACTIVE, None))
+        comp = int(bool(getattr(problem, "is_compressible", False)))   # material_model.is_compressible()
         for l, lev in enumerate(hier.levels):
-            self._set_coeff(l, problem.eta_levels[l])
-        self._set_coeff(ACTIVE, problem.eta_active, dilation=getattr(problem, "dilation", None))
+            self._set_coeff(l, problem.eta_levels[l], is_compressible=comp)
+        self._set_coeff(ACTIVE, problem.eta_active, is_compressible=comp, dilation=getattr(problem, "dilation", None))
         if getattr(problem, "free_surface", None) is not None:
             self.set_free_surface_faces(*problem.free_surface)
         if not single_level:

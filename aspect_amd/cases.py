@@ -78,6 +78,8 @@ class StokesProblem:
     # deviatoric and carries -lambda^2 int L p q in its pressure block.  dilation_rhs / dilation_lhs: x -> R, L
     dilation_rhs: callable = None
     dilation_lhs: callable = None
+    # material_model.is_compressible(): every operator carries the -2/3 eta div u term (matrix_free_operators.cc:243-246)
+    is_compressible: bool = False
 
     def _hierarchy(self, only_finest):
         if self.make_hierarchy is not None:
@@ -470,6 +472,27 @@ def poiseuille_2d(refinement=4):
         eta=lambda x: np.ones(x.shape[0]), force=lambda x: np.zeros_like(x),
         averaging=bm.AVG_HARMONIC, pressure_scaling=1.0 / (0.01 * X), extents=[X, Y],
         tol=1e-6, restart=100, n_cheap=200, n_expensive=0, boundary_traction={0: traction, 1: traction})
+
+
+def simple_compressibility_box(refinement=3):
+    """tests/simple_compressibility_iterated_stokes_gmg.prm (+ simple_compressibility_iterated_stokes.prm): unit box, the
+    `simple compressible` material (rho = rho0 exp(beta p), rho0 = 0.90909..., beta = 0.01, eta = 1), vertical gravity 10,
+    free slip on the sides, inflow (0, 1) through the bottom, open top; isentropic compression, harmonic averaging.  The
+    density and with it both right-hand sides depend on the iterate: tests/solution_checks.py drives the iterated-Stokes
+    loop and fills rhs_u / rhs_p per nonlinear iteration."""
+    def inflow(x):
+        u = np.zeros_like(x)
+        u[:, 1] = 1.0
+        return u
+
+    p = StokesProblem(
+        name=f"simple_compressibility_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_TANGENTIAL, bm.BC_TANGENTIAL, bm.BC_ZERO, bm.BC_NONE],
+        eta=lambda x: np.ones(x.shape[0]), force=lambda x: np.zeros_like(x),
+        averaging=bm.AVG_HARMONIC, pressure_scaling=1.0 / 0.01, extents=[1.0, 1.0],
+        tol=1e-7, restart=100, n_cheap=1000, n_expensive=1000, boundary_velocity=inflow, is_compressible=True)
+    p.rho0, p.beta, p.gravity = 0.909090909090, 0.01, np.array([0.0, -10.0])
+    return p
 
 
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))

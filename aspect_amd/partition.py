@@ -166,7 +166,7 @@ class LocalProblem:
         self.g = gproblem
         self.rank, self.size = rank, size
         for k in ("name", "dim", "tol", "restart", "n_cheap", "n_expensive", "krylov", "idr_s",
-                  "pressure_scaling", "eta_min", "eta_max"):
+                  "pressure_scaling", "eta_min", "eta_max", "is_compressible"):
             setattr(self, k, getattr(gproblem, k, None))
         self.hier = LocalHierarchy(gproblem.hier, rank, size)
         self.eta_levels = [np.ascontiguousarray(t[lev.cells]) for t, lev in zip(gproblem.eta_levels, self.hier.levels)]

@@ -12,7 +12,8 @@ REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", "nsinker_gmg_idr",
          "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
          "particle_interpolator_bilinear_3d", "periodic_box_gmg", "nsinker_gmg_gc",
-         "poiseuille_2d_pressure_bc_gmg", "prescribed_dilation_gmg", "geometric_average_only_viscosity", "free_surface_blob_gmg"]
+         "poiseuille_2d_pressure_bc_gmg", "prescribed_dilation_gmg", "geometric_average_only_viscosity", "free_surface_blob_gmg",
+         "simple_compressibility_iterated_stokes_gmg"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 

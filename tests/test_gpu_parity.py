@@ -725,6 +725,16 @@ def test_free_surface_blob_first_solve_golden(hip_lib):
     assert rc == 0 and rep.n_cheap_iterations == 0 and rep.n_expensive_iterations == so["expensive"]
 
 
+def test_simple_compressibility_iterated_stokes_golden(hip_lib, oracle_lib):
+    """tests/simple_compressibility_iterated_stokes_gmg through the HIP library (compressible operators on all levels, five
+    nonlinear iterations from non-zero start vectors): same checks as the oracle test, and the same iteration counts as the
+    oracle."""
+    ho = sc.solve_simple_compressibility(lambda p: capi.Solver(hip_lib, p))
+    sc.check_simple_compressibility(GOLD["simple_compressibility_iterated_stokes_gmg"], *ho)
+    oo = sc.solve_simple_compressibility(lambda p: capi.Solver(oracle_lib, p))
+    assert [r.n_cheap_iterations for r, _, _ in ho[1]] == [r.n_cheap_iterations for r, _, _ in oo[1]]
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

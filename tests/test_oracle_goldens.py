@@ -439,6 +439,15 @@ def test_free_surface_blob_first_solve_golden():
     assert rc == 0 and rep.n_cheap_iterations == so["cheap"] == 0 and rep.n_expensive_iterations == so["expensive"]
 
 
+def test_simple_compressibility_iterated_stokes_golden():
+    """tests/simple_compressibility_iterated_stokes_gmg: compressible material (rho = rho0 exp(beta p)), isentropic compression,
+    inflow through the bottom, open top, five iterated-Stokes steps.  Pins the compressible operators on every level, the
+    compressible term of correct_stokes_rhs (local_smoothing.cc:837-840), the pressure right-hand side of
+    assemblers/stokes.cc:729-758 and non-zero start vectors: the relative nonlinear residuals in 5-6 digits, `Top/bottom flux:
+    1/1`; iteration counts within one of 11/7/6/5/4 (see solution_checks.check_simple_compressibility)."""
+    sc.check_simple_compressibility(G["simple_compressibility_iterated_stokes_gmg"], *sc.solve_simple_compressibility(pyoracle.solver))
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
