@@ -13,7 +13,7 @@ CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", 
          "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
          "particle_interpolator_bilinear_3d", "periodic_box_gmg", "nsinker_gmg_gc",
          "poiseuille_2d_pressure_bc_gmg", "prescribed_dilation_gmg", "geometric_average_only_viscosity", "free_surface_blob_gmg",
-         "simple_compressibility_iterated_stokes_gmg"]
+         "simple_compressibility_iterated_stokes_gmg", "prescribed_dilation_newton"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 
@@ -28,6 +28,9 @@ def parse(path):
         if m:
             parts = [int(x.replace(",", "")) for x in m.group(2).split("+")]
             out["meshes"][-1]["dofs_u"], out["meshes"][-1]["dofs_p"] = parts[0], parts[1]
+        m = re.search(r"Initial Newton Stokes residual = (\S+), v = (\S+), p = (\S+)", line)
+        if m:
+            out.setdefault("initial_newton_residuals", []).append([float(m.group(i)) for i in range(1, 4)])
         if "Solving Stokes system (GMG" in line:
             cur = {"mesh": len(out.get("meshes", [])) - 1}
             out["solves"].append(cur)
@@ -54,7 +57,7 @@ def parse(path):
         m = re.search(r"A block preconditioner: (\d+)\+(\d+) iterations", line)
         if m:
             cur["A_cheap"], cur["A_expensive"] = int(m.group(1)), int(m.group(2))
-        m = re.search(r"Relative nonlinear residual \(Stokes system\) after nonlinear iteration (\d+): (\S+)", line)
+        m = re.search(r"Relative nonlinear residual \((?:Stokes|total) system\) after nonlinear iteration (\d+): (\S+)", line)
         if m:
             out.setdefault("nonlinear_residuals", []).append(float(m.group(2)))
         m = re.search(r"RMS, max velocity:\s+(\S+) m/s, (\S+) m/s", line)

@@ -345,3 +345,35 @@ def check_simple_compressibility(gold, p, out, u, pn):
     for k, ((_, _, rel), g) in enumerate(zip(out, gold["nonlinear_residuals"])):
         assert abs(rel / g - 1.0) < (1e-5 if k < 3 else 1e-3), (k, rel, g)
     assert float("%.4g" % density_flux(p, u, pn, 3)) == 1.0 and float("%.4g" % density_flux(p, u, pn, 2)) == 1.0
+
+
+def solve_and_check_prescribed_dilation_newton(gold, solver_factory, mesh, stokes_op):
+    """tests/prescribed_dilation_newton (`iterated Advection and Newton Stokes` on the deck of prescribed_dilation.prm: no
+    cheap steps, tolerance 1e-12): the first nonlinear iteration solves the plain system (solver_schemes.cc:553-571), so the
+    `Initial Newton Stokes residual` is the norm of the corrected right-hand side and of its blocks; 0+23 / 0+25 FGMRES
+    iterations with the inner CG solves; the second residual (7.9e-13 / 3.5e-13, below which the scheme skips the solve) is the
+    true residual of that solve; errors to 6 digits."""
+    from aspect_amd import cases
+    p = cases.prescribed_dilation_2d(3 + mesh)
+    p.n_cheap = 0
+    p.build()
+    fin, m = p.hier.finest, gold["meshes"][mesh]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    nu = fin.n_dofs_v
+    s = solver_factory(p)
+    rhs = s.rhs_correction(p.u0, np.concatenate([p.rhs_u, p.rhs_p]))
+    norms = [np.linalg.norm(rhs), np.linalg.norm(rhs[:nu]), np.linalg.norm(rhs[nu:])]
+    for a, b in zip(norms, gold["initial_newton_residuals"][mesh]):
+        assert float("%.6g" % a) == b, (norms, gold["initial_newton_residuals"][mesh])
+    x, rep, rc = s.solve(rhs=rhs)
+    res = np.linalg.norm(rhs - s.vmult(stokes_op, x)) / norms[0]
+    s.close()
+    so = gold["solves"][mesh]
+    assert rc == 0 and rep.n_cheap_iterations == 0 and rep.n_expensive_iterations == so["expensive"]
+    assert res < 1e-12 and 0.2 < res / gold["nonlinear_residuals"][2 * mesh + 1] < 5.0, res
+    x = x.copy()
+    x[:nu] += p.u0[:nu]
+    eu, ep = analytic_l2_errors(p, x)
+    gu, gp = gold["errors_uL2_pL2"][mesh]
+    assert abs(eu / gu - 1.0) < 2e-6 and abs(ep / gp - 1.0) < 2e-6, (eu, ep, gu, gp)

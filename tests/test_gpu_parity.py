@@ -735,6 +735,13 @@ def test_simple_compressibility_iterated_stokes_golden(hip_lib, oracle_lib):
     assert [r.n_cheap_iterations for r, _, _ in ho[1]] == [r.n_cheap_iterations for r, _, _ in oo[1]]
 
 
+@pytest.mark.parametrize("mesh", [0, 1])
+def test_prescribed_dilation_newton_golden(mesh, hip_lib):
+    """tests/prescribed_dilation_newton through the HIP library: FGMRES with the inner CG solves on the dilation operator,
+    0+23 / 0+25 iterations, initial residuals and errors as the reference prints them."""
+    sc.solve_and_check_prescribed_dilation_newton(GOLD["prescribed_dilation_newton"], lambda p: capi.Solver(hip_lib, p), mesh, capi.OP_STOKES)
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -448,6 +448,13 @@ def test_simple_compressibility_iterated_stokes_golden():
     sc.check_simple_compressibility(G["simple_compressibility_iterated_stokes_gmg"], *sc.solve_simple_compressibility(pyoracle.solver))
 
 
+@pytest.mark.parametrize("mesh", [0, 1])
+def test_prescribed_dilation_newton_golden(mesh):
+    """tests/prescribed_dilation_newton: expensive solver only with the dilation terms (0+23 / 0+25), initial Newton residuals
+    955.927 (325.491, 898.806) / 805.147 (450.858, 667.075) in every printed digit, errors to 6 digits."""
+    sc.solve_and_check_prescribed_dilation_newton(G["prescribed_dilation_newton"], pyoracle.solver, mesh, capi.OP_STOKES)
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
