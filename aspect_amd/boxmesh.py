@@ -78,6 +78,7 @@ def _morton_decode(m, dim, nbits):
 
 
 BC_NONE, BC_ZERO, BC_TANGENTIAL = 0, 1, 2
+BC_COMPONENTS = 16      # BC_COMPONENTS + bits: the velocity components in `bits` are constrained (`bottom x: function`)
 
 
 class Level:
@@ -199,6 +200,8 @@ class Level:
                     mask[on] |= allbits
                 elif code == BC_TANGENTIAL:
                     mask[on] |= (1 << d)
+                elif code >= BC_COMPONENTS:
+                    mask[on] |= (code - BC_COMPONENTS) & allbits
         return mask if self.lex_of_v is None else mask[self.lex_of_v]
 
     def qpoint_coords(self):
@@ -353,8 +356,9 @@ def _dgq1_restriction(dim):
     return np.stack(out)
 
 
-def viscosity_tables(hier, eta_func, averaging):
-    """Return (active_table, [level tables], eta_min, eta_max).
+def viscosity_tables(hier, eta_func, averaging, eta_q=None):
+    """Return (active_table, [level tables], eta_min, eta_max).  eta_q: the viscosity at the q-points of the finest
+    level [n_cells][3^dim] in place of eta_func (solution-dependent rheologies).
 
     Tables are ``[n_cells][1]`` (DGQ0) or ``[n_cells][3^dim]`` (per q-point)
     exactly as OperatorCellData::viscosity's second extent
@@ -362,7 +366,8 @@ def viscosity_tables(hier, eta_func, averaging):
     """
     dim = hier.dim
     fin = hier.finest
-    eta_q = eta_func(fin.qpoint_coords().reshape(-1, dim)).reshape(fin.n_cells, -1)
+    if eta_q is None:
+        eta_q = eta_func(fin.qpoint_coords().reshape(-1, dim)).reshape(fin.n_cells, -1)
     eta_min, eta_max = float(eta_q.min()), float(eta_q.max())
     nL = hier.n_levels
     ch = 1 << dim

@@ -495,6 +495,31 @@ def simple_compressibility_box(refinement=3):
     return p
 
 
+def nonlinear_channel_flow_tractions(refinement=4):
+    """tests/nonlinear_channel_flow_tractions_Newton_Stokes_GMG.prm (benchmarks/newton_solver_benchmark_set/
+    nonlinear_channel_flow/input_t.prm + input_v.prm): box 10 km x 8 km from one coarse cell, no slip on the sides,
+    u_x = 0 on top and bottom with the traction (0, 1e9) on the bottom and (0, 0) on the top (`bottom y: function`), no
+    gravity, power-law rheology `simple nonlinear` (n = 3, A = 1e-37, 1e19 <= eta <= 1e24), harmonic averaging, linear
+    tolerance 1e-7.  The viscosity depends on the iterate: tests/solution_checks.py drives the defect-correction Picard /
+    Newton loop; the tables built here are those of the first iteration (u = 0: eta = 1e24)."""
+    X, Y = 10e3, 8e3
+
+    def traction(x):
+        t = np.zeros_like(x)
+        t[:, 1] = np.where(x[:, 1] > 4e3, 0.0, 1e9)
+        return t
+
+    p = StokesProblem(
+        name=f"nonlinear_channel_tractions_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_ZERO, bm.BC_ZERO, bm.BC_COMPONENTS + 1, bm.BC_COMPONENTS + 1],
+        eta=lambda x: np.full(x.shape[0], 1e24), force=lambda x: np.zeros_like(x),
+        averaging=bm.AVG_HARMONIC, pressure_scaling=1e24 / (0.01 * X), extents=[X, Y],
+        tol=1e-7, restart=100, n_cheap=1000, n_expensive=1000, boundary_traction={2: traction, 3: traction})
+    p.rheology = dict(prefactor=1e-37, n=3.0, eta_min=1e19, eta_max=1e24, min_strain_rate=1.96e-40)
+    p.length_scale = 0.01 * X
+    return p
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

@@ -13,7 +13,8 @@ CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", 
          "nsinker_gmg_no_avg", "stokes", "refinement_nonadiabatic_temperature",
          "particle_interpolator_bilinear_3d", "periodic_box_gmg", "nsinker_gmg_gc",
          "poiseuille_2d_pressure_bc_gmg", "prescribed_dilation_gmg", "geometric_average_only_viscosity", "free_surface_blob_gmg",
-         "simple_compressibility_iterated_stokes_gmg", "prescribed_dilation_newton"]
+         "simple_compressibility_iterated_stokes_gmg", "prescribed_dilation_newton",
+         "nonlinear_channel_flow_tractions_Newton_Stokes_GMG"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 
@@ -60,6 +61,13 @@ def parse(path):
         m = re.search(r"Relative nonlinear residual \((?:Stokes|total) system\) after nonlinear iteration (\d+): (\S+)", line)
         if m:
             out.setdefault("nonlinear_residuals", []).append(float(m.group(2)))
+        m = re.search(r"Newton system information: Norm of the rhs: ([^,\s]+)(?:, Derivative scaling factor: (\S+))?", line)
+        if m:
+            out.setdefault("newton_rhs_norms", []).append(float(m.group(1)))
+            out.setdefault("derivative_scaling_factors", []).append(float(m.group(2)) if m.group(2) else None)
+        m = re.search(r"The linear solver tolerance is set to ([^.\s]+(?:\.\d+)?(?:e[-+]?\d+)?)\.", line)
+        if m:
+            out.setdefault("linear_tolerances", []).append(float(m.group(1)))
         m = re.search(r"RMS, max velocity:\s+(\S+) m/s, (\S+) m/s", line)
         if m:
             out.setdefault("rms_max_velocity", []).append([float(m.group(1)), float(m.group(2))])

@@ -742,6 +742,16 @@ def test_prescribed_dilation_newton_golden(mesh, hip_lib):
     sc.solve_and_check_prescribed_dilation_newton(GOLD["prescribed_dilation_newton"], lambda p: capi.Solver(hip_lib, p), mesh, capi.OP_STOKES)
 
 
+def test_nonlinear_channel_flow_newton_golden(hip_lib, oracle_lib):
+    """tests/nonlinear_channel_flow_tractions_Newton_Stokes_GMG through the HIP library: Picard and Newton steps (derivative
+    terms in k_cells<STOKES, NEWTON>), same checks against the reference's output as the oracle, and the oracle's iteration
+    counts in the steps the golden pins."""
+    dh = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p)).run()
+    sc.check_newton_channel(GOLD["nonlinear_channel_flow_tractions_Newton_Stokes_GMG"], dh)
+    do = sc.NewtonChannelDriver(lambda p: capi.Solver(oracle_lib, p)).run()
+    assert [e["cheap"] for e in dh.log[:6]] == [e["cheap"] for e in do.log[:6]]
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -455,6 +455,14 @@ def test_prescribed_dilation_newton_golden(mesh):
     sc.solve_and_check_prescribed_dilation_newton(G["prescribed_dilation_newton"], pyoracle.solver, mesh, capi.OP_STOKES)
 
 
+def test_nonlinear_channel_flow_newton_golden():
+    """tests/nonlinear_channel_flow_tractions_Newton_Stokes_GMG: three defect-correction Picard steps, then seven Newton
+    steps whose Stokes operator carries the symmetrised, SPD-stabilised derivative terms (matrix_free_operators.cc:196-213,
+    249-257, tables of local_smoothing.cc:545-607) with harmonically averaged viscosities.  The first reference golden that
+    pins the Newton-derivative operator: 10 / 11 / 11 iterations of the first three Newton solves and their residuals."""
+    sc.check_newton_channel(G["nonlinear_channel_flow_tractions_Newton_Stokes_GMG"], sc.NewtonChannelDriver(pyoracle.solver).run())
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
