@@ -520,6 +520,28 @@ def nonlinear_channel_flow_tractions(refinement=4):
     return p
 
 
+def nonlinear_channel_flow_velocities(refinement=4):
+    """tests/nonlinear_channel_flow_velocities_Newton_Stokes_GMG.prm (+ nonlinear_channel_flow_velocities_Newton_Stokes.prm):
+    the channel of `nonlinear_channel_flow_tractions` with the analytic power-law profile prescribed as velocity on top and
+    bottom (all boundaries Dirichlet: the pressure is fixed up to a constant), minimum strain rate 1e-16, the rheology on
+    the deviator of the strain rate, linear tolerance 1e-6; 30 defect-correction Picard steps (the Newton switch is off)."""
+    X, Y, n = 10e3, 8e3, 3.0
+
+    def profile(x):
+        u = np.zeros_like(x)
+        u[:, 1] = (1e-37 / (n + 1)) * ((1e9 / 8e3) ** n) * ((5e3) ** (n + 1) - (x[:, 0] - 5e3) ** (n + 1))
+        return u
+
+    p = StokesProblem(
+        name=f"nonlinear_channel_velocities_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_ZERO] * 4,
+        eta=lambda x: np.full(x.shape[0], 1e24), force=lambda x: np.zeros_like(x),
+        averaging=bm.AVG_HARMONIC, pressure_scaling=1e24 / (0.01 * X), extents=[X, Y],
+        tol=1e-6, restart=100, n_cheap=1000, n_expensive=1000, boundary_velocity=profile)
+    p.rheology = dict(prefactor=1e-37, n=n, eta_min=1e19, eta_max=1e24, min_strain_rate=1e-16, use_deviator=True)
+    p.length_scale = 0.01 * X
+    return p
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

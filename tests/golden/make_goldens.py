@@ -14,7 +14,9 @@ CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", 
          "particle_interpolator_bilinear_3d", "periodic_box_gmg", "nsinker_gmg_gc",
          "poiseuille_2d_pressure_bc_gmg", "prescribed_dilation_gmg", "geometric_average_only_viscosity", "free_surface_blob_gmg",
          "simple_compressibility_iterated_stokes_gmg", "prescribed_dilation_newton",
-         "nonlinear_channel_flow_tractions_Newton_Stokes_GMG"]
+         "nonlinear_channel_flow_tractions_Newton_Stokes_GMG",
+         "nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG",
+         "nonlinear_channel_flow_velocities_Newton_Stokes_GMG"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 

@@ -391,6 +391,8 @@ def power_law_viscosity(rheo, eps):
     """benchmarks/newton_solver_benchmark_set/nonlinear_channel_flow/simple_nonlinear.cc:104-126 (one field, `Use deviator
     of strain-rate = false`): eta = clip(A^(-1/n) (2 max(sqrt(e:e / 2), e_min))^(1/n - 1)) and d eta / d eps =
     (1/n - 1) eta e / (e:e) where nothing clips, else 0.  eps [..., 2, 2] -> (eta [...], deta [..., 2, 2])."""
+    if rheo.get("use_deviator", False):
+        eps = eps - (np.einsum("...ii->...", eps) / eps.shape[-1])[..., None, None] * np.eye(eps.shape[-1])
     ee = np.einsum("...ij,...ij->...", eps, eps)
     strict = np.sqrt(0.5 * ee)
     ninv = 1.0 / rheo["n"]
@@ -411,9 +413,9 @@ class NewtonChannelDriver:
     Eisenstat-Walker tolerance (helper_functions.cc:2636-2666), the line search and the surface pressure normalisation."""
 
     def __init__(self, solver_factory, refinement=4, max_pre_newton=3, max_line_search=5, max_linear_tolerance=1e-2,
-                 spd_safety=0.9):
+                 spd_safety=0.9, case="nonlinear_channel_flow_tractions"):
         from aspect_amd import cases
-        self.p = p = cases.nonlinear_channel_flow_tractions(refinement).build()
+        self.p = p = getattr(cases, case)(refinement).build()
         self.factory = solver_factory
         self.fin = fin = p.hier.finest
         self.nu = fin.n_dofs_v
@@ -461,17 +463,16 @@ class NewtonChannelDriver:
         return s, newton
 
     def newton_rhs(self, s, x):
-        """f - A(eta(u)) x with the Picard coefficients the solver holds; constrained rows are zero (u vanishes there)."""
-        from aspect_amd import capi
-        r = self.b - s.vmult(capi.OP_STOKES, x)
-        r[:self.nu][self.fin.constrained_dofs_v()] = 0.0
-        return r
+        """f - A(eta(u)) x with the Picard coefficients the solver holds: x is read with its boundary values (no constraints),
+        the constrained rows are dropped, which is what agmg_rhs_correction does with `u0`."""
+        return s.rhs_correction(x, self.b)
 
     def run(self, n_nonlinear=10, verbose=False):
         from aspect_amd import capi
         p, fin, nu = self.p, self.fin, self.nu
         u, pn = np.zeros(nu), np.zeros(fin.n_dofs_p)        # velocity, unscaled normalised pressure
-        initial = float(np.linalg.norm(self.b))              # compute_initial_newton_residual: u = 0, p = 0
+        ubc = np.zeros(nu + fin.n_dofs_p) if p.u0 is None else p.u0
+        initial = None                                       # compute_initial_newton_residual: u = boundary values, p = 0
         residual = residual_old = initial
         switch_initial, for_scaling = 1.0, 1.0
         use_picard, relative, lin_res = True, np.inf, np.nan
@@ -483,10 +484,13 @@ class NewtonChannelDriver:
             lam = self.pressure_scaling(u)
             if it == 0:
                 s, _ = self.make_solver(u, lam, tol, 0.0)
-                x, rep, rc = s.solve(rhs=self.b, x0=np.zeros(nu + fin.n_dofs_p))
+                rhs0 = s.rhs_correction(ubc, self.b)           # correct_stokes_rhs: the inhomogeneous boundary values
+                self.initial_parts = (float(np.linalg.norm(rhs0[:nu])), float(np.linalg.norm(rhs0[nu:])))
+                initial = float(np.linalg.norm(rhs0))
+                x, rep, rc = s.solve(rhs=rhs0, x0=np.zeros(nu + fin.n_dofs_p))
                 s.close()
                 residual = residual_old = rep.initial_nonlinear_residual
-                u, pn = x[:nu].copy(), x[nu:] * lam
+                u, pn = x[:nu] + ubc[:nu], x[nu:] * lam
                 printed = residual
             else:
                 s, newton = self.make_solver(u, lam, tol, scale)
@@ -575,3 +579,57 @@ def check_newton_channel(gold, d, exact_solves=6):
     fl = gold["mass_fluxes"][0]
     for b in range(4):
         assert abs(boundary_mass_flux(p, x, b, density=rho) - fl[b]) < 2.1e-4, (b, boundary_mass_flux(p, x, b, density=rho), fl[b])
+
+
+def check_dc_picard_channel(gold, d):
+    """tests/nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG/screen-output (`iterated defect correction Stokes`: ten
+    Picard steps at tolerance 1e-7): every iteration count (13 / 12 / 14 / 16 / 16 / 17 / 17 / 18 / 18 / 18), every norm of the
+    right-hand side and relative residual in the six printed digits, RMS / max velocity 1.96e-08 / 2.33e-08, pressure average
+    and maximum, mass fluxes -+0.6176."""
+    p, fin, m = d.p, d.fin, gold["meshes"][0]
+    assert fin.n_cells == m["cells"] and fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    assert float("%.6g" % d.initial) == gold["initial_newton_residuals"][0][0]
+    assert len(d.log) == len(gold["solves"]) == 10
+    for k, (e, so) in enumerate(zip(d.log, gold["solves"])):
+        assert e["rc"] == 0 and e["expensive"] == 0 and e["cheap"] == so["cheap"], (k, e["cheap"], so["cheap"])
+        assert e["scale"] == 0.0 and e["tol"] == 1e-7
+        assert abs(e["norm_rhs"] / gold["newton_rhs_norms"][k] - 1.0) < 2e-6, (k, e["norm_rhs"], gold["newton_rhs_norms"][k])
+        assert abs(e["relative"] / gold["nonlinear_residuals"][k] - 1.0) < 5e-6, (k, e["relative"])
+    x = np.concatenate([d.u, d.pn / p.pressure_scaling])
+    rms, vmax = rms_max_velocity(p, x)
+    g_rms, g_max = gold["rms_max_velocity"][0]
+    assert float("%.3g" % rms) == g_rms and float("%.3g" % vmax) == g_max, (rms, vmax)
+    assert float("%.4g" % d.pn.max()) == gold["pressure_min_avg_max"][0][2] and abs(d.pn.min()) < 10.0
+    rho = 3300.0 * (1.0 + 3.5e-5 * 293.0)
+    for b in range(4):
+        assert abs(boundary_mass_flux(p, x, b, density=rho) - gold["mass_fluxes"][0][b]) < 5.1e-5
+
+
+def check_velocities_channel(gold, d):
+    """tests/nonlinear_channel_flow_velocities_Newton_Stokes_GMG/screen-output, time step 0 (the later steps need the
+    temperature solve): the initial Newton residual 6.67966e+16 (v 4.5894e+16, p 4.85338e+16: correct_stokes_rhs with the
+    prescribed profile), all 30 iteration counts (12, 17, 17, 18 x 17, 17 x 10), the norms of the right-hand side to 1e-4
+    (each is the difference of numbers 1e5 times larger that the solve before it fixed to 1e-6), RMS / max velocity, pressure
+    minimum / average / maximum and mass fluxes as printed.  All boundaries are Dirichlet: the pressure constant is a null
+    space of the system, fixed only by the surface normalisation."""
+    p, fin, m = d.p, d.fin, gold["meshes"][0]
+    assert fin.n_cells == m["cells"] and fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    g0 = gold["initial_newton_residuals"][0]
+    assert [float("%.6g" % v) for v in (d.initial,) + d.initial_parts] == g0, (d.initial, d.initial_parts)
+    assert len(d.log) == 30
+    for k, (e, so) in enumerate(zip(d.log, gold["solves"][:30])):
+        assert e["rc"] == 0 and e["expensive"] == 0 and e["cheap"] == so["cheap"], (k, e["cheap"], so["cheap"])
+        assert e["scale"] == 0.0 and e["tol"] == 1e-6
+        assert abs(e["norm_rhs"] / gold["newton_rhs_norms"][k] - 1.0) < 1e-4, (k, e["norm_rhs"], gold["newton_rhs_norms"][k])
+    x = np.concatenate([d.u, d.pn / p.pressure_scaling])
+    rms, vmax = rms_max_velocity(p, x)
+    g_rms, g_max = gold["rms_max_velocity"][0]
+    assert float("%.3g" % rms) == g_rms and float("%.3g" % vmax) == g_max, (rms, vmax)           # 2.57e-08, 3.05e-08
+    pmin, pavg, pmax = gold["pressure_min_avg_max"][0]
+    N1q = bm.tensor_shape([bm.N1] * 2)
+    W = bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * 2).reshape(-1)
+    avg = ((d.pn[fin.cell_nodes_p.astype(np.int64)] @ N1q.T) * W).sum() / (W.sum() * fin.n_cells)
+    assert [float("%.4g" % v) for v in (d.pn.min(), avg, d.pn.max())] == [pmin, pavg, pmax], (d.pn.min(), avg, d.pn.max())
+    rho = 3300.0 * (1.0 + 3.5e-5 * 293.0)
+    for b in range(4):
+        assert abs(boundary_mass_flux(p, x, b, density=rho) - gold["mass_fluxes"][0][b]) < 5.1e-5

@@ -752,6 +752,21 @@ def test_nonlinear_channel_flow_newton_golden(hip_lib, oracle_lib):
     assert [e["cheap"] for e in dh.log[:6]] == [e["cheap"] for e in do.log[:6]]
 
 
+def test_nonlinear_channel_flow_dc_picard_golden(hip_lib):
+    """tests/nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG through the HIP library: all ten iteration counts and
+    residual norms of the reference in every printed digit."""
+    sc.check_dc_picard_channel(GOLD["nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG"],
+                               sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), max_pre_newton=1000).run())
+
+
+def test_nonlinear_channel_flow_velocities_golden(hip_lib):
+    """tests/nonlinear_channel_flow_velocities_Newton_Stokes_GMG through the HIP library: all 30 iteration counts of time
+    step 0, residual norms and printed statistics."""
+    d = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), max_pre_newton=1000,
+                               case="nonlinear_channel_flow_velocities").run(n_nonlinear=30)
+    sc.check_velocities_channel(GOLD["nonlinear_channel_flow_velocities_Newton_Stokes_GMG"], d)
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

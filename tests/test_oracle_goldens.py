@@ -463,6 +463,22 @@ def test_nonlinear_channel_flow_newton_golden():
     sc.check_newton_channel(G["nonlinear_channel_flow_tractions_Newton_Stokes_GMG"], sc.NewtonChannelDriver(pyoracle.solver).run())
 
 
+def test_nonlinear_channel_flow_dc_picard_golden():
+    """tests/nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG: ten defect-correction Picard steps on the power-law
+    rheology, solve(solve_newton_system = true) each time: all ten iteration counts and residual norms in every printed
+    digit, velocity and mass-flux statistics as printed."""
+    sc.check_dc_picard_channel(G["nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG"],
+                               sc.NewtonChannelDriver(pyoracle.solver, max_pre_newton=1000).run())
+
+
+def test_nonlinear_channel_flow_velocities_golden():
+    """tests/nonlinear_channel_flow_velocities_Newton_Stokes_GMG, time step 0: 30 defect-correction Picard steps with the
+    analytic profile prescribed on top and bottom (inhomogeneous Dirichlet through correct_stokes_rhs, pressure known up to a
+    constant): every iteration count, residual norms to 1e-4, all printed statistics."""
+    d = sc.NewtonChannelDriver(pyoracle.solver, max_pre_newton=1000, case="nonlinear_channel_flow_velocities").run(n_nonlinear=30)
+    sc.check_velocities_channel(G["nonlinear_channel_flow_velocities_Newton_Stokes_GMG"], d)
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
