@@ -542,6 +542,38 @@ def nonlinear_channel_flow_velocities(refinement=4):
     return p
 
 
+def tosi_benchmark(refinement=4):
+    """tests/tosi_benchmark_gmg_newton_solver.prm (benchmarks/newton_solver_benchmark_set/tosi_et_al_2015/input.prm +
+    benchmarks/tosi_et_al_2015_gcubed/tosi.cc), time step 0: unit box, free slip, gravity 1e8, rho = 1 - 1e-6 T with
+    T = (1 - z) + 0.01 cos(pi x) sin(pi z) interpolated on the Q2 temperature space, visco-plastic Tosi rheology (eta = 0.1
+    where the strain rate vanishes), harmonic averaging (density too), tolerance 1e-6, 200 cheap steps.  Viscosity and both
+    right-hand sides depend on the iterate: tests/solution_checks.py drives the Picard / Newton loop."""
+    pi = 3.1415926536            # the deck's own constant
+
+    def temperature(x):
+        return (1.0 - x[:, 1]) + 0.01 * np.cos(pi * x[:, 0]) * np.sin(pi * x[:, 1])
+
+    def force_q(level):
+        Tq = level.nodal_to_qpoints(temperature(level.node_coords_v()))
+        rho = 1.0 * (1.0 - 1e-6 * (Tq - 0.0))
+        rho = np.repeat((rho.shape[1] / (1.0 / rho).sum(axis=1))[:, None], rho.shape[1], axis=1)
+        f = np.zeros(rho.shape + (2,))
+        f[:, :, 1] = -1e8 * rho
+        return f
+
+    p = StokesProblem(
+        name=f"tosi_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_TANGENTIAL] * 4,
+        eta=lambda x: np.full(x.shape[0], 0.1), force=None, force_q=force_q,
+        averaging=bm.AVG_HARMONIC, pressure_scaling=0.1 / 0.01, extents=[1.0, 1.0],
+        tol=1e-6, restart=100, n_cheap=200, n_expensive=1000,
+        initial_pressure=lambda x: 1e8 * (1.0 - x[:, 1]))          # adiabatic profile of rho = 1 (compute_profile.cc)
+    p.temperature = temperature
+    p.rheology = dict(kind="tosi", eta_T=1e5, eta_Z=10.0, sigma_yield=1.0, eta_asterisk=1e-3, eta_initial=1e-1,
+                      eta_min=1e-6, eta_max=10.0)
+    p.length_scale = 0.01
+    return p
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

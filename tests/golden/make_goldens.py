@@ -16,7 +16,8 @@ CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", 
          "simple_compressibility_iterated_stokes_gmg", "prescribed_dilation_newton",
          "nonlinear_channel_flow_tractions_Newton_Stokes_GMG",
          "nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG",
-         "nonlinear_channel_flow_velocities_Newton_Stokes_GMG"]
+         "nonlinear_channel_flow_velocities_Newton_Stokes_GMG",
+         "tosi_benchmark_gmg_newton_solver"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 

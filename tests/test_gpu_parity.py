@@ -767,6 +767,14 @@ def test_nonlinear_channel_flow_velocities_golden(hip_lib):
     sc.check_velocities_channel(GOLD["nonlinear_channel_flow_velocities_Newton_Stokes_GMG"], d)
 
 
+def test_tosi_benchmark_newton_golden(hip_lib):
+    """tests/tosi_benchmark_gmg_newton_solver, time step 0, through the HIP library (buoyancy, visco-plastic rheology, Picard
+    then Newton with Eisenstat-Walker tolerances): see solution_checks.check_tosi."""
+    d = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), case="tosi_benchmark", max_pre_newton=5, max_line_search=0,
+                               max_linear_tolerance=0.9).run(n_nonlinear=7)
+    sc.check_tosi(GOLD["tosi_benchmark_gmg_newton_solver"], d)
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -479,6 +479,13 @@ def test_nonlinear_channel_flow_velocities_golden():
     sc.check_velocities_channel(G["nonlinear_channel_flow_velocities_Newton_Stokes_GMG"], d)
 
 
+def test_tosi_benchmark_newton_golden():
+    """tests/tosi_benchmark_gmg_newton_solver, time step 0: see solution_checks.check_tosi."""
+    d = sc.NewtonChannelDriver(pyoracle.solver, case="tosi_benchmark", max_pre_newton=5, max_line_search=0,
+                               max_linear_tolerance=0.9).run(n_nonlinear=7)
+    sc.check_tosi(G["tosi_benchmark_gmg_newton_solver"], d)
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
