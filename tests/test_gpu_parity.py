@@ -775,6 +775,13 @@ def test_tosi_benchmark_newton_golden(hip_lib):
     sc.check_tosi(GOLD["tosi_benchmark_gmg_newton_solver"], d)
 
 
+def test_tosi_benchmark_dc_picard_golden(hip_lib):
+    """tests/tosi_benchmark_gmg_dc_picard_solver, time step 0, through the HIP library."""
+    d = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), case="tosi_benchmark", max_pre_newton=1000,
+                               max_line_search=0).run(n_nonlinear=8)
+    sc.check_tosi_dc_picard(GOLD["tosi_benchmark_gmg_dc_picard_solver"], d)
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -486,6 +486,12 @@ def test_tosi_benchmark_newton_golden():
     sc.check_tosi(G["tosi_benchmark_gmg_newton_solver"], d)
 
 
+def test_tosi_benchmark_dc_picard_golden():
+    """tests/tosi_benchmark_gmg_dc_picard_solver, time step 0: see solution_checks.check_tosi_dc_picard."""
+    d = sc.NewtonChannelDriver(pyoracle.solver, case="tosi_benchmark", max_pre_newton=1000, max_line_search=0).run(n_nonlinear=8)
+    sc.check_tosi_dc_picard(G["tosi_benchmark_gmg_dc_picard_solver"], d)
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
