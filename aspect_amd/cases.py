@@ -574,6 +574,29 @@ def tosi_benchmark(refinement=4):
     return p
 
 
+def tangurnis_tala(refinement=3):
+    """tests/tangurnis_tala_gmg.prm (benchmarks/tangurnis/tala/tan.prm + code/tangurnis.cc): unit box, free slip, gravity 1,
+    Di = 0.5, gamma = 1, a = 0: eta = Di, rho = -Di T exp(Di depth) with the analytic T = sin(pi y) cos(pi x); truncated
+    anelastic: `Mass conservation = reference density profile` with rho_ref = exp(Di depth); compressible operators, harmonic
+    averaging of the viscosity only.  The pressure right-hand side depends on the iterate (tests/solution_checks.py)."""
+    Di, gamma = 0.5, 1.0
+
+    def force(x):
+        T = np.sin(np.pi * x[:, 1]) * np.cos(np.pi * x[:, 0])
+        rho = Di * (-1.0 * T) * np.exp(Di / gamma * (1.0 - x[:, 1]))
+        f = np.zeros_like(x)
+        f[:, 1] = -1.0 * rho
+        return f
+
+    p = StokesProblem(
+        name=f"tangurnis_tala_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_TANGENTIAL] * 4,
+        eta=lambda x: np.full(x.shape[0], Di), force=force, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=Di / 0.01, extents=[1.0, 1.0], tol=1e-7, restart=100, n_cheap=1000, n_expensive=1000,
+        is_compressible=True)
+    p.Di, p.gamma, p.gravity = Di, gamma, np.array([0.0, -1.0])
+    return p
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

@@ -732,3 +732,57 @@ def check_tosi_dc_picard(gold, d):
     x = np.concatenate([d.u, d.pn / p.pressure_scaling])
     rms, vmax = rms_max_velocity(p, x)
     assert [float("%.3g" % rms), float("%.3g" % vmax)] == gold["rms_max_velocity"][0], (rms, vmax)
+
+
+def solve_tangurnis_tala(solver_factory, refinement=3, n_nonlinear=7, verbose=False):
+    """`no Advection, iterated Stokes` of tests/tangurnis_tala_gmg, time step 0: per nonlinear iteration the pressure
+    right-hand side lambda (1 / rho_ref) (d rho_ref / dz) (g . u) / |g| phi_p of the reference-density formulation
+    (assemblers/stokes.cc:633-643; the derivative by the finite difference of adiabatic_conditions/function.cc:75-83), made
+    compatible with the all-free-slip boundary (helper_functions.cc:1087-1093: minus its sum over the volume times int phi_p),
+    a solve from the denormalised iterate, surface normalisation.  -> (problem, [(report, rc, relative residual)])"""
+    from aspect_amd import cases
+    p = cases.tangurnis_tala(refinement).build()
+    fin, lam = p.hier.finest, p.pressure_scaling
+    nu = fin.n_dofs_v
+    gvec, gmag = p.gravity, np.linalg.norm(p.gravity)
+    N1q, N2q = bm.tensor_shape([bm.N1] * 2), bm.tensor_shape([bm.N2] * 2)
+    W = bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * 2).reshape(-1) * np.prod(fin.h)
+    rho_ref = lambda z: np.exp(p.Di / p.gamma * z)
+    z = 1.0 - fin.qpoint_coords()[:, :, 1]
+    z2 = z + (1e6 * np.finfo(float).eps) * 1.0
+    ratio = ((rho_ref(z) - rho_ref(z2)) / (z - z2)) / rho_ref(z)                # (1 / rho_ref) d rho_ref / dz  [cell][q]
+    phi_int = np.zeros(fin.n_dofs_p)
+    np.add.at(phi_int, fin.cell_nodes_p.astype(np.int64), np.einsum("qi,q->i", N1q, W)[None, :].repeat(fin.n_cells, axis=0))
+    volume = float(np.prod(fin.extents))
+    u, pn, adj = np.zeros(nu), np.zeros(fin.n_dofs_p), 0.0
+    s = solver_factory(p)
+    out, r0 = [], None
+    for it in range(n_nonlinear):
+        uq = np.einsum("qi,cid->cqd", N2q, u.reshape(-1, 2)[fin.cell_nodes_v.astype(np.int64)])
+        loc = np.einsum("qi,q,cq->ci", N1q, W, lam * ratio * (uq @ gvec) / gmag)
+        rhs_p = np.zeros(fin.n_dofs_p)
+        np.add.at(rhs_p, fin.cell_nodes_p.astype(np.int64), loc)
+        rhs_p = rhs_p - (rhs_p.sum() / volume) * phi_int
+        rhs = np.concatenate([p.rhs_u, rhs_p])
+        if it == 0:
+            r0 = np.linalg.norm(rhs)
+        x, rep, rc = s.solve(rhs=rhs, x0=np.concatenate([u, (pn - adj) / lam]))
+        out.append((rep, rc, rep.initial_nonlinear_residual / r0))
+        if verbose:
+            print(it + 1, rep.n_cheap_iterations, rep.n_expensive_iterations, "%.6g" % (rep.initial_nonlinear_residual / r0))
+        u, pn = x[:nu].copy(), x[nu:] * lam
+        adj = surface_pressure_adjustment(fin, pn)
+        pn = pn + adj
+    s.close()
+    return p, out
+
+
+def check_tangurnis_tala(gold, p, out):
+    """tests/tangurnis_tala_gmg/screen-output, time step 0: 8 / 6 / 4 / 3 / 2 / 1 / 1 iterations exactly, the relative nonlinear
+    residuals 1 / 2.1057 / 0.0554202 / 0.00419825 / 0.000165567 / 1.21555e-05 in every printed digit and 6.62258e-07 to 2e-4."""
+    fin, m = p.hier.finest, gold["meshes"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    for k, ((rep, rc, rel), so, g) in enumerate(zip(out, gold["solves"], gold["nonlinear_residuals"])):
+        assert rc == 0 and rep.n_cheap_iterations == so["cheap"] and rep.n_expensive_iterations == 0, (k, rep.n_cheap_iterations)
+        assert abs(rel / g - 1.0) < (3e-6 if k < 6 else 3e-4), (k, rel, g)

@@ -782,6 +782,11 @@ def test_tosi_benchmark_dc_picard_golden(hip_lib):
     sc.check_tosi_dc_picard(GOLD["tosi_benchmark_gmg_dc_picard_solver"], d)
 
 
+def test_tangurnis_tala_golden(hip_lib):
+    """tests/tangurnis_tala_gmg, time step 0, through the HIP library: all seven iteration counts and nonlinear residuals."""
+    sc.check_tangurnis_tala(GOLD["tangurnis_tala_gmg"], *sc.solve_tangurnis_tala(lambda p: capi.Solver(hip_lib, p)))
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -492,6 +492,13 @@ def test_tosi_benchmark_dc_picard_golden():
     sc.check_tosi_dc_picard(G["tosi_benchmark_gmg_dc_picard_solver"], d)
 
 
+def test_tangurnis_tala_golden():
+    """tests/tangurnis_tala_gmg, time step 0 (truncated anelastic: compressible operators on every level, reference-density
+    pressure right-hand side made compatible with the closed boundary, pressure null space): all seven iteration counts
+    and nonlinear residuals."""
+    sc.check_tangurnis_tala(G["tangurnis_tala_gmg"], *sc.solve_tangurnis_tala(pyoracle.solver))
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
