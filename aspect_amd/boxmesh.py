@@ -174,14 +174,21 @@ class Level:
         x = np.stack([idx[d] * (self.h[d] / 2) for d in range(self.dim)], axis=1)
         if self.lex_of_v is not None:
             x = x[self.lex_of_v]
-        return self.deform(x) if self.deform is not None else x
+        return self._deformed(x)
+
+    def _deformed(self, x):
+        """deform(x) for a smooth map of the box, deform(x, level) for maps that depend on the level (the Q1 Eulerian
+        mappings of a deformed mesh: per-level vertex displacements, mesh_deformation/interface.cc:1548-1570)."""
+        if self.deform is None:
+            return x
+        return self.deform(x, self) if getattr(self.deform, "per_level", False) else self.deform(x)
 
     def node_coords_p(self):
         idx = np.indices(tuple(self.npd[::-1])).reshape(self.dim, -1)[::-1]
         x = np.stack([idx[d] * self.h[d] for d in range(self.dim)], axis=1)
         if self.lex_of_p is not None:
             x = x[self.lex_of_p]
-        return self.deform(x) if self.deform is not None else x
+        return self._deformed(x)
 
     def _constraint_mask(self, bc):
         """bc: list of 2*dim codes in deal.II box boundary-id order

@@ -597,6 +597,87 @@ def tangurnis_tala(refinement=3):
     return p
 
 
+def q1_eulerian_deformation(dim, refinement, extents, boundary_displacement):
+    """The mesh of `Mesh deformation` with an initial deformation: the Q1 displacement field that solves the vector Laplace
+    problem of MeshDeformationHandler::compute_mesh_displacements (mesh_deformation/interface.cc:832-985) on the finest mesh
+    with the displacement `boundary_displacement(x) -> [n, dim]` on the top boundary and zero on the others (the zero
+    constraints win in the corners, :821), and the per-level Q1 Eulerian mappings: level vertices carry the fine values
+    (interpolate_to_mg, :1562), every other point of a level cell is mapped bilinearly.  -> deform(x, level), 2-D boxes."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    assert dim == 2
+    n = 1 << refinement
+    hx, hy = extents[0] / n, extents[1] / n
+    nv = n + 1
+    idx = lambda i, j: j * nv + i
+    # Q1 Laplace stiffness of one hx x hy cell (exact for the 2 x 2 Gauss rule)
+    a, b = hy / hx, hx / hy
+    Kx = np.array([[2, -2, 1, -1], [-2, 2, -1, 1], [1, -1, 2, -2], [-1, 1, -2, 2]]) * a / 6.0
+    Ky = np.array([[2, 1, -2, -1], [1, 2, -1, -2], [-2, -1, 2, 1], [-1, -2, 1, 2]]) * b / 6.0
+    Ke = Kx + Ky                                         # local order (0,0), (1,0), (0,1), (1,1)
+    rows, cols, vals = [], [], []
+    for j in range(n):
+        for i in range(n):
+            loc = [idx(i, j), idx(i + 1, j), idx(i, j + 1), idx(i + 1, j + 1)]
+            for r in range(4):
+                for c in range(4):
+                    rows.append(loc[r]); cols.append(loc[c]); vals.append(Ke[r, c])
+    K = sp.csr_matrix((vals, (rows, cols)), shape=(nv * nv, nv * nv))
+    ii, jj = np.meshgrid(np.arange(nv), np.arange(nv), indexing="xy")
+    X = np.stack([ii.reshape(-1) * hx, jj.reshape(-1) * hy], axis=1)
+    on_boundary = (ii == 0) | (ii == n) | (jj == 0) | (jj == n)
+    top = (jj == n) & (ii > 0) & (ii < n)
+    d = np.zeros((nv * nv, 2))
+    d[top.reshape(-1)] = boundary_displacement(X[top.reshape(-1)])
+    free = ~on_boundary.reshape(-1)
+    for c in range(2):
+        rhs = -(K[free][:, ~free] @ d[~free, c])
+        d[free, c] = spla.spsolve(K[free][:, free].tocsc(), rhs)
+    D = d.reshape(nv, nv, 2)                              # [j][i]
+
+    def deform(x, level):
+        m = 1 << level.level                              # cells per direction on this level
+        step = n // m
+        Dl = D[::step, ::step]                            # level vertices: the fine values
+        fx, fy = x[:, 0] / (extents[0] / m), x[:, 1] / (extents[1] / m)
+        ix = np.minimum(np.floor(fx + 1e-12).astype(int), m - 1)
+        iy = np.minimum(np.floor(fy + 1e-12).astype(int), m - 1)
+        tx, ty = (fx - ix)[:, None], (fy - iy)[:, None]
+        disp = ((1 - tx) * (1 - ty) * Dl[iy, ix] + tx * (1 - ty) * Dl[iy, ix + 1]
+                + (1 - tx) * ty * Dl[iy + 1, ix] + tx * ty * Dl[iy + 1, ix + 1])
+        return x + disp
+
+    deform.per_level = True
+    return deform
+
+
+def mesh_deform_prescribed_box(refinement=3):
+    """tests/gmg_mesh_deform_prescribed.prm (+ box_initial_mesh_deformation.prm / .cc): box 660 km x 660 km, top boundary
+    displaced by 20 km cos(2 pi x / 660 km) against gravity before the first time step, no slip everywhere, eta = 1e21,
+    constant temperature (uniform density 3340 (1 - 3e-5 (1613 - 293))), gravity 10: the exact solution is u = 0 with a
+    hydrostatic pressure; the solve starts from the adiabatic pressure rho g depth with depth clipped at the undeformed
+    surface (geometry_model/box.cc:261-273).  Pins the per-level Q1 Eulerian mappings of a deformed mesh."""
+    L = 660000.0
+    rho = 3340.0 * (1.0 - 3e-5 * (1613.0 - 293.0))
+
+    def top(x):
+        d = np.zeros_like(x)
+        d[:, 1] = 20000.0 * np.cos(2.0 * np.pi * x[:, 0] / 660000.0)
+        return d
+
+    def force(x):
+        f = np.zeros_like(x)
+        f[:, 1] = -10.0 * rho
+        return f
+
+    return StokesProblem(
+        name=f"mesh_deform_prescribed_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_ZERO] * 4,
+        eta=lambda x: np.full(x.shape[0], 1e21), force=force, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=1e21 / (0.01 * L), extents=[L, L], tol=1e-7, restart=100, n_cheap=200, n_expensive=1000,
+        deform=q1_eulerian_deformation(2, refinement, [L, L], top),
+        initial_pressure=lambda x: rho * 10.0 * np.clip(L - x[:, 1], 0.0, L))
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

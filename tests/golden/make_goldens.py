@@ -17,7 +17,7 @@ CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", 
          "nonlinear_channel_flow_tractions_Newton_Stokes_GMG",
          "nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG",
          "nonlinear_channel_flow_velocities_Newton_Stokes_GMG",
-         "tosi_benchmark_gmg_newton_solver", "tosi_benchmark_gmg_dc_picard_solver", "tangurnis_tala_gmg"]
+         "tosi_benchmark_gmg_newton_solver", "tosi_benchmark_gmg_dc_picard_solver", "tangurnis_tala_gmg", "gmg_mesh_deform_prescribed"]
 SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
 
 
@@ -74,6 +74,12 @@ def parse(path):
         m = re.search(r"RMS, max velocity:\s+(\S+) m/s, (\S+) m/s", line)
         if m:
             out.setdefault("rms_max_velocity", []).append([float(m.group(1)), float(m.group(2))])
+        m = re.search(r"RMS, max velocity:\s+(\S+) m/year, (\S+) m/year", line)
+        if m:
+            out.setdefault("rms_max_velocity_per_year", []).append([float(m.group(1)), float(m.group(2))])
+        m = re.search(r"Topography min/max:\s+(\S+) m, (\S+) m", line)
+        if m:
+            out.setdefault("topography_min_max", []).append([float(m.group(1)), float(m.group(2))])
         m = re.search(r"Pressure min/avg/max:\s+(\S+) Pa, (\S+) Pa, (\S+) Pa", line)
         if m:
             out.setdefault("pressure_min_avg_max", []).append([float(m.group(i)) for i in range(1, 4)])

@@ -787,6 +787,16 @@ def test_tangurnis_tala_golden(hip_lib):
     sc.check_tangurnis_tala(GOLD["tangurnis_tala_gmg"], *sc.solve_tangurnis_tala(lambda p: capi.Solver(hip_lib, p)))
 
 
+def test_mesh_deform_prescribed_golden(hip_lib):
+    """tests/gmg_mesh_deform_prescribed through the HIP library (general-geometry kernels on every level, each level with the
+    Jacobians of its own Q1 Eulerian mapping): 17+0 iterations."""
+    p = cases.mesh_deform_prescribed_box(3).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    sc.check_mesh_deform_prescribed(GOLD["gmg_mesh_deform_prescribed"], p, x, rep, rc)
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -499,6 +499,16 @@ def test_tangurnis_tala_golden():
     sc.check_tangurnis_tala(G["tangurnis_tala_gmg"], *sc.solve_tangurnis_tala(pyoracle.solver))
 
 
+def test_mesh_deform_prescribed_golden():
+    """tests/gmg_mesh_deform_prescribed: a deformed mesh (initial mesh deformation by a Laplace-smoothed boundary displacement)
+    with its own Q1 Eulerian mapping on every level: 17+0 iterations, topography range, residual velocities to 10 %."""
+    p = cases.mesh_deform_prescribed_box(3).build()
+    s = pyoracle.solver(p)
+    x, rep, rc = s.solve()
+    s.close()
+    sc.check_mesh_deform_prescribed(G["gmg_mesh_deform_prescribed"], p, x, rep, rc)
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
