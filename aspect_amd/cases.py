@@ -80,6 +80,7 @@ class StokesProblem:
     dilation_lhs: callable = None
     # material_model.is_compressible(): every operator carries the -2/3 eta div u term (matrix_free_operators.cc:243-246)
     is_compressible: bool = False
+    eta_q: callable = None              # finest level -> viscosity at its q-points [n_cells, nq] (FE-field viscosities)
 
     def _hierarchy(self, only_finest):
         if self.make_hierarchy is not None:
@@ -92,7 +93,8 @@ class StokesProblem:
         if self.pressure_scaling_from_mesh is not None:
             self.pressure_scaling = self.pressure_scaling_from_mesh(self.hier.finest)
         self.eta_active, self.eta_levels, self.eta_min, self.eta_max = \
-            bm.viscosity_tables(self.hier, self.eta, self.averaging)
+            bm.viscosity_tables(self.hier, self.eta, self.averaging,
+                                eta_q=None if self.eta_q is None else self.eta_q(self.hier.finest))
         fin = self.hier.finest
         self.rhs_u = bm.assemble_rhs_u(fin, self.force, self.force_q)
         for b, traction in (self.boundary_traction or {}).items():
@@ -676,6 +678,59 @@ def mesh_deform_prescribed_box(refinement=3):
         pressure_scaling=1e21 / (0.01 * L), extents=[L, L], tol=1e-7, restart=100, n_cheap=200, n_expensive=1000,
         deform=q1_eulerian_deformation(2, refinement, [L, L], top),
         initial_pressure=lambda x: rho * 10.0 * np.clip(L - x[:, 1], 0.0, L))
+
+
+def crameri_case_1(refinement=1):
+    """tests/crameri_benchmark_1_gmg.prm (benchmarks/crameri_et_al/case_1/crameri_benchmark_1.prm + .cc), first Stokes solve:
+    `rebound box` 2800 km x 700 km of 60 x 15 coarse cells whose vertices are lifted by 7 km cos(2 pi x / X) y / Y (children
+    of a coarse cell are bilinear in it), one global refinement; eta = 1e21 * 100^C with the Q2 composition field C
+    interpolated from `y > 600 km`, rho = 3300, g = 10, free slip on the sides, no slip at the bottom, free surface on top
+    (its stabilisation vanishes with dt = 0); harmonic averaging, no cheap steps, no pressure normalisation; the solve starts
+    from the adiabatic pressure rho g (Y + 7 km - y)."""
+    X, Y, A = 28.0e5, 7.0e5, 7.0e3
+    reps = [60, 15]
+
+    def deform(x, level):
+        # bilinear in the coarse cells: displacement of the coarse vertices, interpolated
+        hx, hy = X / reps[0], Y / reps[1]
+        fx, fy = x[:, 0] / hx, x[:, 1] / hy
+        ix = np.minimum(np.floor(fx + 1e-12).astype(int), reps[0] - 1)
+        iy = np.minimum(np.floor(fy + 1e-12).astype(int), reps[1] - 1)
+        tx, ty = fx - ix, fy - iy
+        lift = lambda i, j: np.cos(2.0 * np.pi * (i * hx) / X) * A * (j * hy) / Y
+        dy = ((1 - tx) * (1 - ty) * lift(ix, iy) + tx * (1 - ty) * lift(ix + 1, iy)
+              + (1 - tx) * ty * lift(ix, iy + 1) + tx * ty * lift(ix + 1, iy + 1))
+        out = x.copy()
+        out[:, 1] += dy
+        return out
+
+    deform.per_level = True
+
+    def eta_of_c(c):
+        return 10.0 ** ((1.0 - c) * np.log10(1e21) + c * np.log10(1e21 * 100.0))
+
+    def eta_q(level):
+        c = np.where(level.node_coords_v()[:, 1] > 600.0e3, 1.0, 0.0)
+        return eta_of_c(level.nodal_to_qpoints(c))
+
+    def scaling(level):
+        mid = np.array([0.5])
+        c = np.where(level.node_coords_v()[:, 1] > 600.0e3, 1.0, 0.0)[level.cell_nodes_v.astype(np.int64)]
+        cm = (c @ bm.tensor_shape([bm.q2_shape(mid)] * 2).T)[:, 0]
+        w = level.jxw.sum(axis=1)
+        return float(np.exp((np.log(eta_of_c(cm)) * w).sum() / w.sum())) / (0.01 * X)
+
+    def force(x):
+        f = np.zeros_like(x)
+        f[:, 1] = -10.0 * 3300.0
+        return f
+
+    return StokesProblem(
+        name=f"crameri_case_1_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_TANGENTIAL, bm.BC_TANGENTIAL, bm.BC_ZERO, bm.BC_NONE],
+        eta=None, eta_q=eta_q, force=force, averaging=bm.AVG_HARMONIC, pressure_scaling=1.0, extents=[X, Y], reps=reps,
+        tol=1e-7, restart=100, n_cheap=0, n_expensive=1000, deform=deform, pressure_scaling_from_mesh=scaling,
+        initial_pressure=lambda x: 3300.0 * 10.0 * (Y + A - x[:, 1]))
 
 
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))

@@ -718,7 +718,7 @@ def test_geometric_average_only_viscosity_golden(hip_lib):
 def test_free_surface_blob_first_solve_golden(hip_lib):
     """tests/free_surface_blob_gmg, first solve: 0+11 iterations (expensive solver only, open top boundary)."""
     p = cases.free_surface_blob_deck(3).build()
-    s = capi.Solver(hip_lib, p)
+    s = capi.Solver(hip_lib, p, A_block_is_symmetric=0)
     x, rep, rc = s.solve()
     s.close()
     so = GOLD["free_surface_blob_gmg"]["solves"][0]
@@ -795,6 +795,19 @@ def test_mesh_deform_prescribed_golden(hip_lib):
     x, rep, rc = s.solve()
     s.close()
     sc.check_mesh_deform_prescribed(GOLD["gmg_mesh_deform_prescribed"], p, x, rep, rc)
+
+
+def test_crameri_case_1_first_solve_golden(hip_lib):
+    """tests/crameri_benchmark_1_gmg, first solve, through the HIP library: FGMRES with BiCGStab on the A block (the free
+    surface makes it unsymmetric for the reference) and CG on the Schur block.  The oracle reproduces the reference's 0+20
+    and stops 4 % under the tolerance; BiCGStab solves stopped at 1e-2 amplify the summation order of the device reductions
+    (the outer history differs in the second digit from the third iteration on) and the HIP solve needs 0+21: asserted to +-1."""
+    p = cases.crameri_case_1(1).build()
+    s = capi.Solver(hip_lib, p, A_block_is_symmetric=0)
+    x, rep, rc = s.solve()
+    s.close()
+    so = GOLD["crameri_benchmark_1_gmg"]["solves"][0]
+    assert rc == 0 and rep.n_cheap_iterations == 0 and abs(rep.n_expensive_iterations - so["expensive"]) <= 1
 
 
 def test_poiseuille_pressure_boundary_golden(hip_lib):

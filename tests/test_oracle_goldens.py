@@ -432,7 +432,7 @@ def test_free_surface_blob_first_solve_golden():
     fin, m = p.hier.finest, g["meshes"][0]
     assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
     assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
-    s = pyoracle.solver(p)
+    s = pyoracle.solver(p, A_block_is_symmetric=0)       # free surface: stokes_A_block_is_symmetric() is false
     x, rep, rc = s.solve()
     s.close()
     so = g["solves"][0]
@@ -507,6 +507,30 @@ def test_mesh_deform_prescribed_golden():
     x, rep, rc = s.solve()
     s.close()
     sc.check_mesh_deform_prescribed(G["gmg_mesh_deform_prescribed"], p, x, rep, rc)
+
+
+def test_crameri_case_1_first_solve_golden():
+    """tests/crameri_benchmark_1_gmg, first solve (dt = 0): 3,600 cells on 2 levels from 60 x 15 lifted coarse cells,
+    29,402+3,751 DoFs, viscosity 1e21 .. 1e23 from a Q2 composition field, free surface on top: stokes_A_block_is_symmetric()
+    is false there (helper_functions.cc:1265-1275), so the expensive preconditioner solves the A block with BiCGStab
+    (stokes_matrix_free.h:321-333): 0+20 iterations with it, 0+17 with CG - the golden tells them apart.  Topography +-7000 m."""
+    g = G["crameri_benchmark_1_gmg"]
+    p = cases.crameri_case_1(1).build()
+    fin, m = p.hier.finest, g["meshes"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"]
+    assert fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    cells, _ = fin.boundary_faces(3)
+    top = fin.node_coords_p()[fin.cell_nodes_p[cells][:, 2:].astype(np.int64).reshape(-1), 1] - 7.0e5
+    assert [float("%.4g" % top.min()), float("%.4g" % top.max())] == g["topography_min_max"][0]
+    s = pyoracle.solver(p, A_block_is_symmetric=0)
+    x, rep, rc = s.solve()
+    s.close()
+    so = g["solves"][0]
+    assert rc == 0 and rep.n_cheap_iterations == so["cheap"] == 0 and rep.n_expensive_iterations == so["expensive"]
+    s = pyoracle.solver(p, A_block_is_symmetric=1)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rep.n_expensive_iterations != so["expensive"]
 
 
 def test_poiseuille_pressure_boundary_golden():
