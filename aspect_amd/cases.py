@@ -445,8 +445,11 @@ def free_surface_blob_deck(refinement=3):
 
     def force_q(level):
         tq = level.nodal_to_qpoints(temperature_nodal(level.node_coords_v()))
+        rho = 3300.0 * (1.0 - 4e-5 * tq)
+        # `Material averaging = harmonic average` averages the density too (material_model/interface.cc:895-896)
+        rho = np.repeat((rho.shape[1] / (1.0 / rho).sum(axis=1))[:, None], rho.shape[1], axis=1)
         f = np.zeros(tq.shape + (2,))
-        f[:, :, 1] = -10.0 * 3300.0 * (1.0 - 4e-5 * tq)
+        f[:, :, 1] = -10.0 * rho
         return f
 
     return StokesProblem(

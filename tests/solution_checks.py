@@ -806,3 +806,22 @@ def check_mesh_deform_prescribed(gold, p, x, rep, rc):
     rms, vmax = rms_max_velocity(p, x)
     g_rms, g_max = gold["rms_max_velocity_per_year"][0]
     assert abs(rms * year / g_rms - 1.0) < 0.1 and abs(vmax * year / g_max - 1.0) < 0.1, (rms * year, vmax * year)
+
+
+def check_free_surface_iterated_stokes(solver_factory, g):
+    """tests/free_surface_iterated_stokes_gmg, first mesh (the deck of free_surface_blob_gmg under `single Advection, iterated
+    Stokes`): 0+11 iterations, relative nonlinear residual 0.000956812 after the first iteration (the buoyancy of the blob with
+    the harmonically averaged density over the whole right-hand side), 0+0 and about 2.5e-11 in the second."""
+    from aspect_amd import cases
+    p = cases.free_surface_blob_deck(3).build()
+    fin, m = p.hier.finest, g["meshes"][0]
+    assert fin.n_cells == m["cells"] and fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    s = solver_factory(p)
+    r0 = np.linalg.norm(np.concatenate([p.rhs_u, p.rhs_p]))
+    x, rep, rc = s.solve()
+    x2, rep2, rc2 = s.solve(x0=x)
+    s.close()
+    assert rc == 0 and (rep.n_cheap_iterations, rep.n_expensive_iterations) == (g["solves"][0]["cheap"], g["solves"][0]["expensive"])
+    assert float("%.6g" % (rep.initial_nonlinear_residual / r0)) == g["nonlinear_residuals"][0]
+    assert rc2 == 0 and (rep2.n_cheap_iterations, rep2.n_expensive_iterations) == (0, 0)
+    assert 0.2 < rep2.initial_nonlinear_residual / r0 / g["nonlinear_residuals"][1] < 5.0

@@ -810,6 +810,11 @@ def test_crameri_case_1_first_solve_golden(hip_lib):
     assert rc == 0 and rep.n_cheap_iterations == 0 and abs(rep.n_expensive_iterations - so["expensive"]) <= 1
 
 
+def test_free_surface_iterated_stokes_golden(hip_lib):
+    """tests/free_surface_iterated_stokes_gmg, first mesh, through the HIP library: 0+11, 0.000956812, then 0+0."""
+    sc.check_free_surface_iterated_stokes(lambda p: capi.Solver(hip_lib, p, A_block_is_symmetric=0), GOLD["free_surface_iterated_stokes_gmg"])
+
+
 def test_poiseuille_pressure_boundary_golden(hip_lib):
     """tests/poiseuille_2d_pressure_bc_gmg (prescribed boundary tractions): the HIP solve reproduces the
     reference's iteration counts, velocities, pressures and mass fluxes to the digits printed."""

@@ -533,6 +533,11 @@ def test_crameri_case_1_first_solve_golden():
     assert rep.n_expensive_iterations != so["expensive"]
 
 
+def test_free_surface_iterated_stokes_golden():
+    """tests/free_surface_iterated_stokes_gmg, first mesh: see solution_checks.check_free_surface_iterated_stokes."""
+    sc.check_free_surface_iterated_stokes(lambda p: pyoracle.solver(p, A_block_is_symmetric=0), G["free_surface_iterated_stokes_gmg"])
+
+
 def test_poiseuille_pressure_boundary_golden():
     """tests/poiseuille_2d_pressure_bc_gmg: prescribed boundary tractions (open inlet and outlet) enter the
     right-hand side as int_Gamma phi . t dS; 256 cells on 5 levels, 2,178+289 DoFs, coarse sizes 18 / 4,
