@@ -437,9 +437,10 @@ def tosi_viscosity_and_derivative(rheo, eps, T):
     return eta, deta
 
 
-class NewtonChannelDriver:
-    """`single Advection, iterated Newton Stokes` (solver_schemes.cc:1125-1221 and do_one_defect_correction_Stokes_step,
-    :534-839) on cases.nonlinear_channel_flow_tractions, restated on the host the way Simulator does it around the solver:
+class NewtonStokesDriver:
+    """`single Advection, iterated Newton Stokes` / `iterated Advection and Newton Stokes` / `iterated defect correction
+    Stokes` (solver_schemes.cc:1125-1221, 1446-1587 and do_one_defect_correction_Stokes_step, :534-839) on the solution-dependent
+    cases of aspect_amd/cases.py (`case`: power-law channel with tractions or velocities, Tosi benchmark), restated on the host the way Simulator does it around the solver:
     pressure scaling from the midpoint viscosities of the iterate (helper_functions.cc:252-320), harmonically averaged cell
     viscosities, the Newton right-hand side f - A(eta(u)) x (assemblers/newton_stokes.cc:377-386), the Newton tables of
     local_smoothing.cc:545-607 (deviatoric strain rate, averaging weights (eta_avg / eta_q)^2 / n_q, SPD factor), the
@@ -575,10 +576,9 @@ class NewtonChannelDriver:
                 switch_initial = for_scaling = residual
             else:
                 for_scaling = 0.0
-            if it != 0:
-                pn = pn + surface_pressure_adjustment(fin, pn)
-            else:
-                pn = pn + surface_pressure_adjustment(fin, pn)      # solve() normalises its solution (local_smoothing.cc:1541)
+            # surface normalisation: solve() normalises its solution in the first iteration (local_smoothing.cc:1541), the
+            # scheme the updated linearisation point in the later ones (solver_schemes.cc:832-833)
+            pn = pn + surface_pressure_adjustment(fin, pn)
             relative = residual / initial
             self.log.append(dict(cheap=rep.n_cheap_iterations, expensive=rep.n_expensive_iterations, rc=rc, norm_rhs=printed,
                                  relative=relative, scale=scale, tol=tol, lam=lam, line_search=(0 if it == 0 else ls),

@@ -746,9 +746,9 @@ def test_nonlinear_channel_flow_newton_golden(hip_lib, oracle_lib):
     """tests/nonlinear_channel_flow_tractions_Newton_Stokes_GMG through the HIP library: Picard and Newton steps (derivative
     terms in k_cells<STOKES, NEWTON>), same checks against the reference's output as the oracle, and the oracle's iteration
     counts in the steps the golden pins."""
-    dh = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p)).run()
+    dh = sc.NewtonStokesDriver(lambda p: capi.Solver(hip_lib, p)).run()
     sc.check_newton_channel(GOLD["nonlinear_channel_flow_tractions_Newton_Stokes_GMG"], dh)
-    do = sc.NewtonChannelDriver(lambda p: capi.Solver(oracle_lib, p)).run()
+    do = sc.NewtonStokesDriver(lambda p: capi.Solver(oracle_lib, p)).run()
     assert [e["cheap"] for e in dh.log[:6]] == [e["cheap"] for e in do.log[:6]]
 
 
@@ -756,13 +756,13 @@ def test_nonlinear_channel_flow_dc_picard_golden(hip_lib):
     """tests/nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG through the HIP library: all ten iteration counts and
     residual norms of the reference in every printed digit."""
     sc.check_dc_picard_channel(GOLD["nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG"],
-                               sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), max_pre_newton=1000).run())
+                               sc.NewtonStokesDriver(lambda p: capi.Solver(hip_lib, p), max_pre_newton=1000).run())
 
 
 def test_nonlinear_channel_flow_velocities_golden(hip_lib):
     """tests/nonlinear_channel_flow_velocities_Newton_Stokes_GMG through the HIP library: all 30 iteration counts of time
     step 0, residual norms and printed statistics."""
-    d = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), max_pre_newton=1000,
+    d = sc.NewtonStokesDriver(lambda p: capi.Solver(hip_lib, p), max_pre_newton=1000,
                                case="nonlinear_channel_flow_velocities").run(n_nonlinear=30)
     sc.check_velocities_channel(GOLD["nonlinear_channel_flow_velocities_Newton_Stokes_GMG"], d)
 
@@ -770,14 +770,14 @@ def test_nonlinear_channel_flow_velocities_golden(hip_lib):
 def test_tosi_benchmark_newton_golden(hip_lib):
     """tests/tosi_benchmark_gmg_newton_solver, time step 0, through the HIP library (buoyancy, visco-plastic rheology, Picard
     then Newton with Eisenstat-Walker tolerances): see solution_checks.check_tosi."""
-    d = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), case="tosi_benchmark", max_pre_newton=5, max_line_search=0,
+    d = sc.NewtonStokesDriver(lambda p: capi.Solver(hip_lib, p), case="tosi_benchmark", max_pre_newton=5, max_line_search=0,
                                max_linear_tolerance=0.9).run(n_nonlinear=7)
     sc.check_tosi(GOLD["tosi_benchmark_gmg_newton_solver"], d)
 
 
 def test_tosi_benchmark_dc_picard_golden(hip_lib):
     """tests/tosi_benchmark_gmg_dc_picard_solver, time step 0, through the HIP library."""
-    d = sc.NewtonChannelDriver(lambda p: capi.Solver(hip_lib, p), case="tosi_benchmark", max_pre_newton=1000,
+    d = sc.NewtonStokesDriver(lambda p: capi.Solver(hip_lib, p), case="tosi_benchmark", max_pre_newton=1000,
                                max_line_search=0).run(n_nonlinear=8)
     sc.check_tosi_dc_picard(GOLD["tosi_benchmark_gmg_dc_picard_solver"], d)
 

@@ -460,7 +460,7 @@ def test_nonlinear_channel_flow_newton_golden():
     steps whose Stokes operator carries the symmetrised, SPD-stabilised derivative terms (matrix_free_operators.cc:196-213,
     249-257, tables of local_smoothing.cc:545-607) with harmonically averaged viscosities.  The first reference golden that
     pins the Newton-derivative operator: 10 / 11 / 11 iterations of the first three Newton solves and their residuals."""
-    sc.check_newton_channel(G["nonlinear_channel_flow_tractions_Newton_Stokes_GMG"], sc.NewtonChannelDriver(pyoracle.solver).run())
+    sc.check_newton_channel(G["nonlinear_channel_flow_tractions_Newton_Stokes_GMG"], sc.NewtonStokesDriver(pyoracle.solver).run())
 
 
 def test_nonlinear_channel_flow_dc_picard_golden():
@@ -468,27 +468,27 @@ def test_nonlinear_channel_flow_dc_picard_golden():
     rheology, solve(solve_newton_system = true) each time: all ten iteration counts and residual norms in every printed
     digit, velocity and mass-flux statistics as printed."""
     sc.check_dc_picard_channel(G["nonlinear_channel_flow_tractions_dc_picard_Stokes_GMG"],
-                               sc.NewtonChannelDriver(pyoracle.solver, max_pre_newton=1000).run())
+                               sc.NewtonStokesDriver(pyoracle.solver, max_pre_newton=1000).run())
 
 
 def test_nonlinear_channel_flow_velocities_golden():
     """tests/nonlinear_channel_flow_velocities_Newton_Stokes_GMG, time step 0: 30 defect-correction Picard steps with the
     analytic profile prescribed on top and bottom (inhomogeneous Dirichlet through correct_stokes_rhs, pressure known up to a
     constant): every iteration count, residual norms to 1e-4, all printed statistics."""
-    d = sc.NewtonChannelDriver(pyoracle.solver, max_pre_newton=1000, case="nonlinear_channel_flow_velocities").run(n_nonlinear=30)
+    d = sc.NewtonStokesDriver(pyoracle.solver, max_pre_newton=1000, case="nonlinear_channel_flow_velocities").run(n_nonlinear=30)
     sc.check_velocities_channel(G["nonlinear_channel_flow_velocities_Newton_Stokes_GMG"], d)
 
 
 def test_tosi_benchmark_newton_golden():
     """tests/tosi_benchmark_gmg_newton_solver, time step 0: see solution_checks.check_tosi."""
-    d = sc.NewtonChannelDriver(pyoracle.solver, case="tosi_benchmark", max_pre_newton=5, max_line_search=0,
+    d = sc.NewtonStokesDriver(pyoracle.solver, case="tosi_benchmark", max_pre_newton=5, max_line_search=0,
                                max_linear_tolerance=0.9).run(n_nonlinear=7)
     sc.check_tosi(G["tosi_benchmark_gmg_newton_solver"], d)
 
 
 def test_tosi_benchmark_dc_picard_golden():
     """tests/tosi_benchmark_gmg_dc_picard_solver, time step 0: see solution_checks.check_tosi_dc_picard."""
-    d = sc.NewtonChannelDriver(pyoracle.solver, case="tosi_benchmark", max_pre_newton=1000, max_line_search=0).run(n_nonlinear=8)
+    d = sc.NewtonStokesDriver(pyoracle.solver, case="tosi_benchmark", max_pre_newton=1000, max_line_search=0).run(n_nonlinear=8)
     sc.check_tosi_dc_picard(G["tosi_benchmark_gmg_dc_picard_solver"], d)
 
 
