@@ -162,6 +162,27 @@ struct agmg_ctx {
   std::vector<double *> bicg_pool;  // three more velocity vectors for BiCGStab on a non-symmetric A block
   int nA = 0, nS = 0;          // V-cycle / inner iteration counters of the current preconditioner
   std::vector<double> h0, h1;  // host staging for the coarse level
+  // pinned staging of the host-resident coarse solve, per block: [0, n) the defect, [n, 2n) the solution.  The solve runs
+  // as a host function in stream order (hipLaunchHostFunc): no synchronisation, and the V-cycle stays capturable
+  double *coarse_pin[2] = {nullptr, nullptr};
+  size_t coarse_pin_cap[2] = {0, 0};
+  struct CoarseJob { agmg_ctx *c; int which; } coarse_job[2];
+  void coarse_host_compute(int which, const double *b, double *xout) const;
+  // one hipGraph per V-cycle (A block, Schur block): the cycle is a fixed sequence of some hundred small launches on
+  // fixed buffers.  Opt-in (AGMG_GRAPHS=1): measured on MI355X the replay saves 3 % of the A-block cycle and 10 % of the
+  // Schur cycle at r5 (the cycles are bound by the dependent kernels' own latency, not by the host's launches), and
+  // rocprofv3 --kernel-trace of ROCm 7.2 segfaults on a process that captures (profiles/README.md).  state: 0 = not run yet (the
+  // first cycle runs eagerly: lazy allocations and kernel attributes), 1 = capture at the next cycle, 2 = replay,
+  // -1 = capture failed, eager from then on
+  bool use_graphs = false;
+  struct VGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int state = 0; } vgraph[2];
+  void free_graphs() {
+    for (auto &g : vgraph) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      if (g.graph) (void)hipGraphDestroy(g.graph);
+      g = VGraph();
+    }
+  }
 
   // ---- distributed contexts: transport callbacks + host staging
   agmg_comm comm{};
@@ -1124,15 +1145,18 @@ int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
   return 0;
 }
 
-// level 0: MGCoarseGridApplySmoother = smoother apply (local_smoothing.cc:999-1004)
-int agmg_ctx::coarse_solve(int which) {
-  if (!coarse_host(which)) return smoother_apply(which, 0, mg_def[which][0]);
+namespace {
+void coarse_host_fn(void *p) {
+  auto *job = static_cast<agmg_ctx::CoarseJob *>(p);
+  const int n = job->c->coarse[job->which].n;
+  job->c->coarse_host_compute(job->which, job->c->coarse_pin[job->which], job->c->coarse_pin[job->which] + n);
+}
+}  // namespace
+
+void agmg_ctx::coarse_host_compute(int which, const double *b, double *xout) const {
   const CoarseOp &co = coarse[which];
   const Smoother &s = sm[which][0];
   const int n = co.n, steps = which == 0 ? 1 : opt.schur_smoother_steps;
-  h0.resize(n);
-  CHECK(d2h(h0.data(), mg_def[which][0], n));
-  const std::vector<double> &b = h0;
   std::vector<double> x(n), xo(n, 0.0), t(n);
   auto matvec = [&](std::vector<double> &y, const std::vector<double> &v) {
     for (int i = 0; i < n; ++i) {
@@ -1169,7 +1193,20 @@ int agmg_ctx::coarse_solve(int which) {
     update(true, 0.0, 1.0 / s.theta);
     recurrence(false);
   }
-  return h2d(mg_sol[which][0], x.data(), n);
+  for (int i = 0; i < n; ++i) xout[i] = x[i];
+}
+
+// level 0: MGCoarseGridApplySmoother = smoother apply (local_smoothing.cc:999-1004)
+int agmg_ctx::coarse_solve(int which) {
+  if (!coarse_host(which)) return smoother_apply(which, 0, mg_def[which][0]);
+  // defect to the host, Jacobi-Chebyshev on the dense operator there, solution back: three stream-ordered nodes
+  const size_t n = (size_t)coarse[which].n;
+  if (coarse_pin_cap[which] < 2 * n) { set_error("coarse_solve: staging not allocated (setup_smoothers)"); return -1; }
+  coarse_job[which] = {this, which};
+  AGMG_HIP_CHECK(hipMemcpyAsync(coarse_pin[which], mg_def[which][0], n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  AGMG_HIP_CHECK(hipLaunchHostFunc(stream, coarse_host_fn, &coarse_job[which]));
+  AGMG_HIP_CHECK(hipMemcpyAsync(mg_sol[which][0], coarse_pin[which] + n, n * sizeof(double), hipMemcpyHostToDevice, stream));
+  return 0;
 }
 
 // Multigrid::level_v_step; uniformly refined meshes: no edge matrices
@@ -1205,11 +1242,35 @@ int agmg_ctx::level_v_step(int which, int l) {
 // PreconditionMG::vmult on device vectors of the active (= finest) mesh
 int agmg_ctx::vcycle(int which, double *dst, const double *src) {
   const int top = nl() - 1;
+  VGraph &g = vgraph[which];
+  if (use_graphs && !dist() && g.state > 0) {
+    // replay (or capture, then replay) on the cycle's own defect buffer: the source moves from call to call
+    CHECK(vec_copy(stream, mg_def[which][top], src, size_of(which, top)));
+    if (g.state == 1) {
+      int rc = 0;
+      if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = -1;
+      else {
+        rc = level_v_step(which, top);
+        hipGraph_t graph = nullptr;
+        if (hipStreamEndCapture(stream, &graph) != hipSuccess || !graph) rc = rc ? rc : -1;
+        if (!rc && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = -1;
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); g.exec = nullptr; }
+        else g.graph = graph;
+      }
+      if (rc) { (void)hipGetLastError(); g.state = -1; }
+      else g.state = 2;
+    }
+    if (g.state == 2) {
+      AGMG_HIP_CHECK(hipGraphLaunch(g.exec, stream));
+      return vec_copy(stream, dst, mg_sol[which][top], size_of(which, top));
+    }
+  }
   double *saved = mg_def[which][top];
   mg_def[which][top] = const_cast<double *>(src);  // read-only at the top level
   const int rc = level_v_step(which, top);
   mg_def[which][top] = saved;
   CHECK(rc);
+  if (use_graphs && !dist() && g.state == 0) g.state = 1;
   return vec_copy(stream, dst, mg_sol[which][top], size_of(which, top));
 }
 
@@ -1451,10 +1512,21 @@ int agmg_ctx::setup_smoothers() {
   CHECK(ensure_workspace());
   CHECK(ensure_transfers());
   CHECK(ensure_mg_vectors());
+  CHECK(sync());
+  free_graphs();           // smoother coefficients are kernel arguments of the captured cycles
   std::vector<std::pair<int, int>> batch;
   for (int w = 0; w < 2; ++w)
     for (int l = 0; l < nl(); ++l) {
-      if (l == 0 && coarse_host(w)) CHECK(build_coarse(w));
+      if (l == 0 && coarse_host(w)) {
+        CHECK(build_coarse(w));
+        const size_t need = 2 * (size_t)coarse[w].n;
+        if (coarse_pin_cap[w] < need) {
+          if (coarse_pin[w]) (void)hipHostFree(coarse_pin[w]);
+          coarse_pin[w] = nullptr; coarse_pin_cap[w] = 0;
+          AGMG_HIP_CHECK(hipHostMalloc((void **)&coarse_pin[w], need * sizeof(double)));
+          coarse_pin_cap[w] = need;
+        }
+      }
       else if (!dist() && use_batched_setup) batch.emplace_back(w, l);
       else CHECK(estimate_device(w, l));
     }
@@ -1976,6 +2048,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (const char *e = getenv("AGMG_BRICK_Z")) c->brick_z_override = atoi(e);
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_GRAPHS")) c->use_graphs = atoi(e) != 0;
   if (const char *e = getenv("AGMG_NO_BATCHED_SETUP")) c->use_batched_setup = atoi(e) == 0;
   c->L.resize(opt->n_levels);
   c->H.resize(opt->n_levels);
@@ -2029,6 +2102,8 @@ void agmg_destroy(agmg_ctx *c) {
   c->dfree(c->dot_partials); c->dfree(c->dot_out_d);
   if (c->dot_out_h) (void)hipHostFree(c->dot_out_h);
   if (c->stage_h) (void)hipHostFree(c->stage_h);
+  c->free_graphs();
+  for (int w = 0; w < 2; ++w) if (c->coarse_pin[w]) (void)hipHostFree(c->coarse_pin[w]);
   rccl_comm_destroy(c->rccl_state);
   if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
   if (c->ev_src_ready) (void)hipEventDestroy(c->ev_src_ready);

@@ -893,3 +893,28 @@ def test_hollow_sphere_golden_on_the_gpu(hip_lib):
     velocities, 33+0 iterations, the reference's relative residuals and analytic error norms."""
     from test_oracle_goldens import _solve_hollow_sphere, check_hollow_sphere
     check_hollow_sphere(*_solve_hollow_sphere(lambda p: capi.Solver(hip_lib, p)))
+
+
+def test_vcycle_graph_replay_matches_eager_launches(hip_lib, monkeypatch):
+    """AGMG_GRAPHS=1: both V-cycles are captured into hipGraphs after their first eager run (the host-resident coarse solve
+    is a host-function node between two copies) and replayed: the same kernels on the same buffers, so the solve repeats the
+    eager one exactly, also after the coefficients changed (the graphs are dropped with the smoothers)."""
+    p = cases.nsinker_box(3, n_sinkers=4, ratio=1e4).build()
+    s = capi.Solver(hip_lib, p)
+    xe, re_, _ = s.solve()
+    s.close()
+    monkeypatch.setenv("AGMG_GRAPHS", "1")
+    s = capi.Solver(hip_lib, p)
+    for _ in range(3):                    # eager, capture + replay, replay
+        xg, rg, _ = s.solve()
+        assert rg.n_cheap_iterations == re_.n_cheap_iterations and np.array_equal(xg, xe)
+    for l in range(p.hier.n_levels):      # new coefficients: smoothers and graphs are rebuilt
+        s._set_coeff(l, 2.0 * p.eta_levels[l])
+    s._set_coeff(capi.ACTIVE, 2.0 * p.eta_active)
+    s._check(s.lib.compute_diagonals(s.ctx))
+    x2, r2, _ = s.solve()
+    x3, r3, _ = s.solve()
+    s.close()
+    assert r2.n_cheap_iterations == r3.n_cheap_iterations and np.array_equal(x2, x3)
+    nu = p.hier.finest.n_dofs_v
+    assert relerr(x2[:nu], 0.5 * xe[:nu]) < 1e-3        # twice the viscosity: half the velocity, to the solver tolerance
