@@ -302,6 +302,9 @@ struct agmg_ctx {
   void program_vmult(const Smoother &s, SmootherProgram &p) const;
   void program_step(const Smoother &s, SmootherProgram &p) const;
   bool fused_mass(int l) const { return use_fused && L[l].mass_fusable; }
+  // A block on a level that is one workgroup: the Chebyshev sequence (and the residual behind it) in one launch
+  bool fused_A(int l) const { return use_fused && use_blocks && !dist() && blk_seq_possible(L[l], L[l].coeff); }
+  int smooth_A_seq(int l, bool zero_start, const double *rhs, double *resid_dst);
   void free_level(DeviceLevel &l);
   void free_coeff(CoeffData &cd) {
     dfree(cd.etaT); dfree(cd.nw_strain); dfree(cd.nw_dEde); dfree(cd.nw_dEdp);
@@ -1121,6 +1124,37 @@ void agmg_ctx::program_step(const Smoother &s, SmootherProgram &p) const {
   }
 }
 
+// cheb_vmult (zero_start) or cheb_step of the A block as one launch on a single-block level; resid_dst: also
+// resid_dst = rhs - A x behind it (the defect Multigrid::level_v_step restricts).  Same steps, vectors and swaps as the
+// launch-per-step forms above.
+int agmg_ctx::smooth_A_seq(int l, bool zero_start, const double *rhs, double *resid_dst) {
+  const Smoother &sp = sm[0][l];
+  double *&x = mg_sol[0][l], *&xo = mg_tmp[0][l];
+  SeqArgs q;
+  q.n_dofs = (int)size_of(0, l);
+  q.b = rhs; q.dinv = L[l].inv_diag_A;
+  auto push = [&](int kind, double f1, double f2, const double *xin, const double *xold, double *dst) {
+    SeqStep &st = q.s[q.n++];
+    st.kind = kind; st.f1 = f1; st.f2 = f2; st.x = xin; st.xold = xold; st.dst = dst;
+  };
+  const bool recur = !(sp.degree < 2 || std::fabs(sp.delta) < 1e-40);
+  if (sp.degree + 2 > SEQ_MAX_STEPS) { set_error("smooth_A_seq: smoother degree too large"); return -1; }
+  if (zero_start) push(SEQ_POINTWISE, 0.0, 1.0 / sp.theta, nullptr, nullptr, x);
+  else { push(SEQ_CHEB, 0.0, 1.0 / sp.theta, x, nullptr, xo); std::swap(x, xo); }
+  if (recur) {
+    double rhok = sp.delta / sp.theta;
+    const double sigma = sp.theta / sp.delta;
+    for (int k = 0; k < sp.degree - 1; ++k) {
+      const double rhokp = 1.0 / (2.0 * sigma - rhok);
+      push(SEQ_CHEB, rhokp * rhok, 2.0 * rhokp / sp.delta, x, (zero_start && k == 0) ? nullptr : xo, xo);
+      rhok = rhokp;
+      std::swap(x, xo);
+    }
+  }
+  if (resid_dst) push(SEQ_RESID, 0.0, 0.0, x, nullptr, resid_dst);
+  return launch_op_seq(stream, L[l], L[l].coeff, q, slots_u);
+}
+
 // mg::SmootherRelaxation(steps): apply = vmult + (steps-1) step; smooth = steps x step
 int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
@@ -1130,6 +1164,7 @@ int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
     for (int i = 1; i < steps; ++i) program_step(sm[1][l], p);
     return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, nullptr, mg_sol[1][l], nullptr, mass_ell(L[l], L[l].coeff));
   }
+  if (which == 0 && fused_A(l)) return smooth_A_seq(l, true, rhs, nullptr);
   CHECK(cheb_vmult(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   for (int i = 1; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   return 0;
@@ -1141,6 +1176,7 @@ int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
     for (int i = 0; i < steps; ++i) program_step(sm[1][l], p);
     return launch_mass_smoother(stream, L[l], L[l].coeff, p, L[l].inv_diag_M, rhs, mg_sol[1][l], mg_sol[1][l], nullptr, mass_ell(L[l], L[l].coeff));
   }
+  if (which == 0 && fused_A(l)) return smooth_A_seq(l, false, rhs, nullptr);
   for (int i = 0; i < steps; ++i) CHECK(cheb_step(which, l, mg_sol[which][l], mg_tmp[which][l], rhs));
   return 0;
 }
@@ -1221,6 +1257,8 @@ int agmg_ctx::level_v_step(int which, int l) {
     for (int i = 1; i < sm_steps; ++i) program_step(sm[1][l], p);
     p.s[p.n++] = {0.0, 0.0, SM_RESID, 0};
     CHECK(launch_mass_smoother(stream, F, F.coeff, p, F.inv_diag_M, mg_def[1][l], nullptr, mg_sol[1][l], mg_t[1][l], mass_ell(F, F.coeff)));
+  } else if (which == 0 && fused_A(l)) {
+    CHECK(smooth_A_seq(l, true, mg_def[0][l], mg_t[0][l]));   // pre-smoothing and t = defect - A solution
   } else {
   CHECK(smoother_apply(which, l, mg_def[which][l]));
   {  // t = defect - A solution

@@ -192,6 +192,24 @@ struct EpiArgs {
   double f1 = 0, f2 = 0;
 };
 
+// one-launch Chebyshev sequences of the A block on single-block levels (k_cells_blk_seq)
+enum { SEQ_POINTWISE = 0, SEQ_CHEB = 1, SEQ_RESID = 2, SEQ_MAX_STEPS = 12 };
+struct SeqStep {
+  int kind = SEQ_CHEB;
+  double f1 = 0, f2 = 0;
+  const double *x = nullptr, *xold = nullptr;
+  double *dst = nullptr;
+};
+struct SeqArgs {
+  int n = 0, n_dofs = 0;
+  const double *b = nullptr, *dinv = nullptr;
+  SeqStep s[SEQ_MAX_STEPS];
+};
+struct DeviceLevel;
+struct CoeffData;
+bool blk_seq_possible(const DeviceLevel &L, const CoeffData &cd);
+int launch_op_seq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SeqArgs &q, double *slots_u);
+
 // ---- operator launches (kernels_ops.hip) ----
 // cell kernels write per-cell contributions to `slots`; pull kernels sum them per DoF.
 // which: AGMG_OP_STOKES (reads u,p; writes slots_u, slots_p), AGMG_OP_A (u -> slots_u),

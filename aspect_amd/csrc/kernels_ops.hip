@@ -535,8 +535,7 @@ __device__ __forceinline__ void blk_node_sums(const char *slots_c, const uint4 *
 }
 
 template <int DIM, int OP, bool COMP, bool PERQ, bool GEN>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES)
-k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u) {
+__device__ __forceinline__ void cells_blk_body(const CellArgs &A, const BlkArgs &B, const EpiArgs &E, const int max_u, const int blk) {
   constexpr int NV = KDims<DIM>::NV, NP = KDims<DIM>::NP, CPW = KDims<DIM>::CPW, LROW = KDims<DIM>::LROW;
   constexpr int BC = CPW * WAVES_PER_BLOCK, NT = 64 * WAVES_PER_BLOCK;
   constexpr int MAXU_PT = (BC * NV / 2 + NT - 1) / NT;  // nodes per thread (U <= BC*NV/2, checked on the host)
@@ -561,12 +560,6 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   // XCD affinity: workgroups with the same blockIdx % 8 share an XCD (and its L2), so each of the
   // 8 groups takes a contiguous run of blocks, i.e. a compact part of the mesh whose blocks re-read
   // each other's halo nodes (a speed choice only: any placement is correct)
-#if AGMG_ABLATE & 256
-  const int blk = blockIdx.x;
-#else
-  const int item = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-  const int blk = B.blk_list ? (int)B.blk_list[B.blk_first + item] : item;
-#endif
   const int c0 = blk * BC;
   const int cell_l = c0 + wave * CPW + j;
   const int cell = cell_l < A.n_cells ? cell_l : A.n_cells - 1;
@@ -693,6 +686,45 @@ k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u)
   else if (E.epi == EPI_RESID) blk_node_sums<DIM, EPI_RESID>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
   else blk_node_sums<DIM, EPI_STORE>(smem_c, l_ent, m_node, U, nex, E, B.slots_sh, sbase);
   AGMG_STAMP(5);
+}
+
+template <int DIM, int OP, bool COMP, bool PERQ, bool GEN>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES)
+k_cells_blk(const CellArgs A, const BlkArgs B, const EpiArgs E, const int max_u) {
+#if AGMG_ABLATE & 256
+  const int blk = blockIdx.x;
+#else
+  const int item = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  const int blk = B.blk_list ? (int)B.blk_list[B.blk_first + item] : item;
+#endif
+  cells_blk_body<DIM, OP, COMP, PERQ, GEN>(A, B, E, max_u, blk);
+}
+
+// A level that is ONE block (<= 84 cells in 3-D: no node is shared with another workgroup, no fix-up pass): a whole
+// Chebyshev sequence of the A block, and the residual behind it, in one launch.  The steps are the launches of
+// cheb_vmult / cheb_step (same kernels' body, same epilogues, same vectors): between two of them the workgroup makes its
+// stores visible (agent-scope fence: the next step gathers what other waves wrote) and meets at a barrier.  On these
+// levels a launch is the latency chain of one workgroup (about 10 us) plus the gap to the next launch: eight to nine
+// of them per smoother application, here one.
+template <int DIM, bool COMP, bool PERQ, bool GEN>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, AGMG_CELLS_WAVES)
+k_cells_blk_seq(const CellArgs A0, const BlkArgs B, const SeqArgs S, const int max_u) {
+  constexpr int NT = 64 * WAVES_PER_BLOCK;
+  for (int k = 0; k < S.n; ++k) {
+    const SeqStep st = S.s[k];
+    if (st.kind == SEQ_POINTWISE) {
+      for (int t = threadIdx.x; t < S.n_dofs; t += NT) st.dst[t] = st.f2 * S.dinv[t] * S.b[t];
+    } else {
+      CellArgs A = A0;
+      A.src_u = st.x;
+      EpiArgs E;
+      E.epi = st.kind == SEQ_CHEB ? EPI_CHEB : EPI_RESID;
+      E.dst = st.dst; E.x = st.x; E.b = S.b; E.xold = st.xold; E.dinv = S.dinv; E.f1 = st.f1; E.f2 = st.f2;
+      cells_blk_body<DIM, KOP_A, COMP, PERQ, GEN>(A, B, E, max_u, 0);
+    }
+    __threadfence();
+    __syncthreads();
+  }
 }
 
 struct FixArgs {
@@ -940,6 +972,28 @@ int launch_blk_t(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiAr
   return 0;
 }
 template <int DIM, bool GEN>
+int launch_blk_seq_t(hipStream_t s, const CellArgs &a, const BlkArgs &b, const SeqArgs &q, int max_u, bool comp, bool perq) {
+  const size_t lds = BlkLds<DIM>::total(max_u);
+  const dim3 grid(1), block(64 * WAVES_PER_BLOCK);
+#define AGMG_SEQ_LAUNCH(C, Q)                                                                              \
+  do {                                                                                                     \
+    static size_t lds_set[64] = {0};   /* the attribute is per device */                                   \
+    int dev_ = 0;                                                                                          \
+    AGMG_HIP_CHECK(hipGetDevice(&dev_));                                                                   \
+    if (dev_ < 0 || dev_ >= 64) { set_error("device ordinal out of range"); return -1; }                   \
+    if (lds > lds_set[dev_]) {                                                                             \
+      AGMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_blk_seq<DIM, C, Q, GEN>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+      lds_set[dev_] = lds;                                                                                 \
+    }                                                                                                      \
+    hipLaunchKernelGGL((k_cells_blk_seq<DIM, C, Q, GEN>), grid, block, lds, s, a, b, q, max_u);            \
+  } while (0)
+  if (comp) { if (perq) AGMG_SEQ_LAUNCH(true, true); else AGMG_SEQ_LAUNCH(true, false); }
+  else { if (perq) AGMG_SEQ_LAUNCH(false, true); else AGMG_SEQ_LAUNCH(false, false); }
+#undef AGMG_SEQ_LAUNCH
+  return 0;
+}
+template <int DIM, bool GEN>
 int launch_blk_op(hipStream_t s, const CellArgs &a, const BlkArgs &b, const EpiArgs &e, int n_blocks, int max_u,
                   int which, bool comp, bool perq) {
   if (which == AGMG_OP_A) return launch_blk_t<DIM, KOP_A, GEN>(s, a, b, e, n_blocks, max_u, comp, perq);
@@ -1124,6 +1178,28 @@ int launch_pull_p(hipStream_t s, const DeviceLevel &L, const double *slots, int 
   else if (n_parts == 2) hipLaunchKernelGGL((k_pull<1, 2>), grid, block, 0, s, p);
   else if (n_parts == 3) hipLaunchKernelGGL((k_pull<1, 3>), grid, block, 0, s, p);
   else { set_error("bad n_parts"); return -1; }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+bool blk_seq_possible(const DeviceLevel &L, const CoeffData &cd) {
+  return L.bt.built && L.bt.n_blocks == 1 && L.bt.n_shared_owned == 0 && L.bt.n_shared_slots == 0 && cd.set && L.n_cells > 0 &&
+         !cd.newton && !cd.dilation;
+}
+int launch_op_seq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SeqArgs &q, double *slots_u) {
+  if (!blk_seq_possible(L, cd)) { set_error("launch_op_seq: level is not a single block"); return -1; }
+  if (q.n < 1 || q.n > SEQ_MAX_STEPS) { set_error("launch_op_seq: bad step count"); return -1; }
+  const BlockTables &bt = L.bt;
+  const CellArgs a = make_cell_args(L, cd, nullptr, nullptr, slots_u, nullptr);
+  BlkArgs b{nullptr, reinterpret_cast<const uint4 *>(bt.blk_hdr), bt.unodes, reinterpret_cast<const uint4 *>(bt.uent8), bt.lidT, slots_u,
+            nullptr, 0};
+  const bool perq = cd.nqv > 1;
+  const bool comp = cd.is_compressible != 0;
+  const bool gen = L.geom == AGMG_GEOM_GENERAL;
+  int rc;
+  if (L.dim == 3) rc = gen ? launch_blk_seq_t<3, true>(s, a, b, q, bt.max_unodes, comp, perq) : launch_blk_seq_t<3, false>(s, a, b, q, bt.max_unodes, comp, perq);
+  else rc = gen ? launch_blk_seq_t<2, true>(s, a, b, q, bt.max_unodes, comp, perq) : launch_blk_seq_t<2, false>(s, a, b, q, bt.max_unodes, comp, perq);
+  if (rc) return rc;
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -918,3 +918,21 @@ def test_vcycle_graph_replay_matches_eager_launches(hip_lib, monkeypatch):
     assert r2.n_cheap_iterations == r3.n_cheap_iterations and np.array_equal(x2, x3)
     nu = p.hier.finest.n_dofs_v
     assert relerr(x2[:nu], 0.5 * xe[:nu]) < 1e-3        # twice the viscosity: half the velocity, to the solver tolerance
+
+
+@pytest.mark.parametrize("name", ["nsinker_r2_perq", "nsinker_r2_harmonic", "box2d_r3_freeslip", "deformed3d_r3_perq", "deformed2d_r3_perq"])
+def test_fused_A_block_sequences_match_launch_per_step(name, hip_lib, monkeypatch):
+    """Levels that are one workgroup run the Chebyshev sequences of the A block (and the residual behind the pre-smoothing)
+    in one launch (k_cells_blk_seq: the block kernel's body step after step); bit for bit the launch-per-step V-cycle."""
+    p = PROBLEMS[name]().build()
+    monkeypatch.setenv("AGMG_NO_FUSED", "1")
+    a = capi.Solver(hip_lib, p)
+    monkeypatch.setenv("AGMG_NO_FUSED", "0")
+    b = capi.Solver(hip_lib, p)
+    src = rand_vec(a.size(capi.OP_A), 4, p.hier.finest)
+    for s in (a, b):
+        s.setup_smoothers()
+    va, vb = a.vcycle(capi.OP_A, src), b.vcycle(capi.OP_A, src)
+    assert np.array_equal(va, vb)
+    a.close()
+    b.close()
