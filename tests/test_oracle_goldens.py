@@ -696,3 +696,11 @@ def check_hollow_sphere(p, x, rep, rc, rhs, rep2):
 
 def test_hollow_sphere_golden():
     check_hollow_sphere(*_solve_hollow_sphere(pyoracle.solver))
+
+
+def test_single_stokes_scheme_golden_is_the_no_cheap_one():
+    """tests/solver_scheme_no_advection_single_stokes is the deck of tests/no_cheap_gmg under `no Advection, single Stokes`:
+    the same first solve (0+12) and the same four error norms, which the no_cheap_gmg tests reproduce."""
+    a, b = G["solver_scheme_no_advection_single_stokes"], G["no_cheap_gmg"]
+    assert a["meshes"] == b["meshes"] and a["solves"][0] == b["solves"][0]
+    assert a["errors_uL1_pL1_uL2_pL2"] == b["errors_uL1_pL1_uL2_pL2"]
