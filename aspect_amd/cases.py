@@ -736,6 +736,31 @@ def crameri_case_1(refinement=1):
         initial_pressure=lambda x: 3300.0 * 10.0 * (Y + A - x[:, 1]))
 
 
+def mesh_deform_topo_first_solve(refinement=4):
+    """tests/gmg_mesh_deform_topo.prm, first Stokes solve (t = 0: the mesh is still undeformed): unit box, free slip on top
+    and bottom, no slip on the sides, eta = 1, gravity 1e5, rho = 1 - T with the Q2 interpolant of T = (1 - z) - 0.01
+    cos(pi x) sin(pi z) and harmonic averaging (density too), adiabatic start pressure 1e5 (1 - z); tolerance 1e-7, 200 cheap
+    steps."""
+    pi = 3.1415926536
+
+    def temperature(x):
+        return (1.0 - x[:, 1]) - 0.01 * np.cos(1 * pi * x[:, 0] / 1.0) * np.sin(pi * x[:, 1])
+
+    def force_q(level):
+        rho = 1.0 - level.nodal_to_qpoints(temperature(level.node_coords_v()))
+        rho = np.repeat((rho.shape[1] / (1.0 / rho).sum(axis=1))[:, None], rho.shape[1], axis=1)
+        f = np.zeros(rho.shape + (2,))
+        f[:, :, 1] = -1e5 * rho
+        return f
+
+    return StokesProblem(
+        name=f"mesh_deform_topo_r{refinement}", dim=2, refinement=refinement,
+        bc=[bm.BC_ZERO, bm.BC_ZERO, bm.BC_TANGENTIAL, bm.BC_TANGENTIAL],
+        eta=lambda x: np.ones(x.shape[0]), force=None, force_q=force_q, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=1.0 / 0.01, extents=[1.0, 1.0], tol=1e-7, restart=100, n_cheap=200, n_expensive=1000,
+        initial_pressure=lambda x: 1e5 * (1.0 - x[:, 1]))
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

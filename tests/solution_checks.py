@@ -825,3 +825,17 @@ def check_free_surface_iterated_stokes(solver_factory, g):
     assert float("%.6g" % (rep.initial_nonlinear_residual / r0)) == g["nonlinear_residuals"][0]
     assert rc2 == 0 and (rep2.n_cheap_iterations, rep2.n_expensive_iterations) == (0, 0)
     assert 0.2 < rep2.initial_nonlinear_residual / r0 / g["nonlinear_residuals"][1] < 5.0
+
+
+def check_mesh_deform_topo_first_solve(gold, solver_factory):
+    """tests/gmg_mesh_deform_topo/screen-output, first solve: 12+0 iterations, RMS / max velocity 8.58 / 12.8 m/s."""
+    from aspect_amd import cases
+    p = cases.mesh_deform_topo_first_solve(4).build()
+    fin, m = p.hier.finest, gold["meshes"][0]
+    assert fin.n_cells == m["cells"] and fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    s = solver_factory(p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0 and (rep.n_cheap_iterations, rep.n_expensive_iterations) == (gold["solves"][0]["cheap"], 0)
+    rms, vmax = rms_max_velocity(p, x)
+    assert [float("%.3g" % rms), float("%.3g" % vmax)] == gold["rms_max_velocity"][0], (rms, vmax)

@@ -936,3 +936,8 @@ def test_fused_A_block_sequences_match_launch_per_step(name, hip_lib, monkeypatc
     assert np.array_equal(va, vb)
     a.close()
     b.close()
+
+
+def test_mesh_deform_topo_first_solve_golden(hip_lib):
+    """tests/gmg_mesh_deform_topo, first solve, through the HIP library: 12+0, RMS / max velocity 8.58 / 12.8."""
+    sc.check_mesh_deform_topo_first_solve(GOLD["gmg_mesh_deform_topo"], lambda p: capi.Solver(hip_lib, p))

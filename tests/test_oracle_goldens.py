@@ -704,3 +704,7 @@ def test_single_stokes_scheme_golden_is_the_no_cheap_one():
     a, b = G["solver_scheme_no_advection_single_stokes"], G["no_cheap_gmg"]
     assert a["meshes"] == b["meshes"] and a["solves"][0] == b["solves"][0]
     assert a["errors_uL1_pL1_uL2_pL2"] == b["errors_uL1_pL1_uL2_pL2"]
+
+
+def test_mesh_deform_topo_first_solve_golden():
+    sc.check_mesh_deform_topo_first_solve(G["gmg_mesh_deform_topo"], pyoracle.solver)
