@@ -761,6 +761,38 @@ def mesh_deform_topo_first_solve(refinement=4):
         initial_pressure=lambda x: 1e5 * (1.0 - x[:, 1]))
 
 
+def convection_box_phase_function(refinement=3):
+    """tests/convection_box_phase_function.prm, first Stokes solve: box 1350 km square, free slip, eta = 1e20, gravity 10,
+    `latent heat` material: rho = (1000 + 200 X) (1 - 1e-4 (T - 500)) with the phase function X = (1 + tanh((depth - 675 km
+    + 405 m/K (T - 500 K)) / 54 km)) / 2 (material_model/latent_heat.cc:84-175, utilities.cc:1424-1479: transition by depth,
+    Clapeyron slope -4.05e6 Pa/K over the adiabatic pressure gradient 1e4 Pa/m), T the Q2 interpolant of the deck's
+    error-function profile; only the viscosity is averaged.  Start pressure 1e4 Pa/m x depth."""
+    from scipy.special import erfc
+    H, pi = 1350000.0, 3.1416
+
+    def temperature(x):
+        X, z = x[:, 0], x[:, 1]
+        return (500 + 500 * (erfc(z / (H * 0.1)) - erfc((1 - z / H) / 0.1)) + 10 * np.cos(pi * X / H) * np.sin(pi * z / H)
+                + 10 * np.cos(2 * pi * X / H) * np.sin(pi * z / H) + 10 * np.cos(pi * X / H) * np.sin(2 * pi * z / H)
+                + 10 * np.cos(2 * pi * X / H) * np.sin(2 * pi * z / H))
+
+    def force_q(level):
+        T = level.nodal_to_qpoints(temperature(level.node_coords_v()))
+        depth = np.clip(H - level.qpoint_coords()[:, :, 1], 0.0, H)
+        dev = depth - 675000.0 - (-4050000.0 / 1e4) * (T - 500.0)
+        phase = 0.5 * (1.0 + np.tanh(dev / 54000.0))
+        rho = (1000.0 + 200.0 * phase) * (1.0 - 1e-4 * (T - 500.0))
+        f = np.zeros(rho.shape + (2,))
+        f[:, :, 1] = -10.0 * rho
+        return f
+
+    return StokesProblem(
+        name=f"convection_box_phase_function_r{refinement}", dim=2, refinement=refinement, bc=[bm.BC_TANGENTIAL] * 4,
+        eta=lambda x: np.full(x.shape[0], 1e20), force=None, force_q=force_q, averaging=bm.AVG_HARMONIC,
+        pressure_scaling=1e20 / (0.01 * H), extents=[H, H], tol=1e-7, restart=100, n_cheap=1000, n_expensive=1000,
+        initial_pressure=lambda x: 1e4 * np.clip(H - x[:, 1], 0.0, H))
+
+
 NSINKER_ALL_CENTERS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nsinker_centers.npy"))
 
 

@@ -941,3 +941,12 @@ def test_fused_A_block_sequences_match_launch_per_step(name, hip_lib, monkeypatc
 def test_mesh_deform_topo_first_solve_golden(hip_lib):
     """tests/gmg_mesh_deform_topo, first solve, through the HIP library: 12+0, RMS / max velocity 8.58 / 12.8."""
     sc.check_mesh_deform_topo_first_solve(GOLD["gmg_mesh_deform_topo"], lambda p: capi.Solver(hip_lib, p))
+
+
+def test_convection_box_phase_function_first_solve_golden(hip_lib):
+    """tests/convection_box_phase_function, first solve, through the HIP library: 8+0."""
+    p = cases.convection_box_phase_function(3).build()
+    s = capi.Solver(hip_lib, p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0 and (rep.n_cheap_iterations, rep.n_expensive_iterations) == (GOLD["convection_box_phase_function"]["solves"][0]["cheap"], 0)

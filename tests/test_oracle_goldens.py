@@ -708,3 +708,16 @@ def test_single_stokes_scheme_golden_is_the_no_cheap_one():
 
 def test_mesh_deform_topo_first_solve_golden():
     sc.check_mesh_deform_topo_first_solve(G["gmg_mesh_deform_topo"], pyoracle.solver)
+
+
+def test_convection_box_phase_function_first_solve_golden():
+    """tests/convection_box_phase_function, first solve (`latent heat` material with a depth-defined phase transition in the
+    density): 64 cells on 4 levels, 8+0 iterations (the only Stokes number its golden holds for this solve)."""
+    g = G["convection_box_phase_function"]
+    p = cases.convection_box_phase_function(3).build()
+    fin, m = p.hier.finest, g["meshes"][0]
+    assert fin.n_cells == m["cells"] and p.hier.n_levels == m["levels"] and fin.n_dofs_v == m["dofs_u"] and fin.n_dofs_p == m["dofs_p"]
+    s = pyoracle.solver(p)
+    x, rep, rc = s.solve()
+    s.close()
+    assert rc == 0 and (rep.n_cheap_iterations, rep.n_expensive_iterations) == (g["solves"][0]["cheap"], 0)
