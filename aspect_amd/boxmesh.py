@@ -412,7 +412,13 @@ def viscosity_tables(hier, eta_func, averaging, eta_q=None):
         return eta_q.copy(), levels, eta_min, eta_max
     if averaging == AVG_PROJECT_Q1:
         Nq, proj = _dgq1_tables(dim)
-        nodal = eta_q @ proj.T                         # [cell][2^dim]
+        if getattr(fin, "general", False):
+            # the cellwise L2 projection carries the cell's own JxW (compute_projection_matrix, material_model/interface.cc)
+            M = np.einsum("qi,cq,qj->cij", Nq, fin.jxw, Nq)
+            rhs = np.einsum("qi,cq,cq->ci", Nq, fin.jxw, eta_q)
+            nodal = np.linalg.solve(M, rhs[:, :, None])[:, :, 0]
+        else:
+            nodal = eta_q @ proj.T                     # [cell][2^dim]
         R = _dgq1_restriction(dim)
         levels = [None] * nL
         cur = nodal

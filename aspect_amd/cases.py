@@ -852,23 +852,37 @@ def nsinker_shell(refinement, n_sinkers=5, ratio=1e2, jump=100.0, averaging="har
         pressure_scaling_from_mesh=scaling)
 
 
+def _hollow_sphere_constants(m):
+    R1, R2, gam = 0.5, 1.0, 1.0
+    if m == -1:
+        alpha = -gam * (R2 ** 3 - R1 ** 3) / (R2 ** 3 * np.log(R1) - R1 ** 3 * np.log(R2))
+        beta = -3 * gam * (np.log(R2) - np.log(R1)) / (R1 ** 3 * np.log(R2) - R2 ** 3 * np.log(R1))
+    else:
+        alpha = gam * (m + 1) * (R1 ** -3 - R2 ** -3) / (R1 ** (-m - 4) - R2 ** (-m - 4))
+        beta = -3 * gam * (R1 ** (m + 1) - R2 ** (m + 1)) / (R1 ** (m + 4) - R2 ** (m + 4))
+    return R1, R2, gam, alpha, beta
+
+
 def hollow_sphere_solution(x, m=-1):
     """Analytic velocity [n][3] and pressure [n] of the hollow-sphere benchmark (Thieulot, Solid Earth
-    2017, viscosity parameter m = -1: mu = 1) as benchmarks/hollow_sphere/hollow_sphere.cc:47-128
-    evaluates it: gamma = 1, R1 = 0.5, R2 = 1, g = 1, rho_0 = 1000."""
-    assert m == -1
-    R1, R2, gam = 0.5, 1.0, 1.0
+    2017, viscosity mu = r^(m+1)) as benchmarks/hollow_sphere/hollow_sphere.cc:47-128 evaluates it:
+    gamma = 1, R1 = 0.5, R2 = 1, g = 1, rho_0 = 1000."""
+    R1, R2, gam, alpha, beta = _hollow_sphere_constants(m)
     r = np.linalg.norm(x, axis=1)
     theta = np.arccos(np.clip(x[:, 2] / r, -1.0, 1.0))
     phi = np.arctan2(x[:, 1], x[:, 0])
-    alpha = -gam * (R2 ** 3 - R1 ** 3) / (R2 ** 3 * np.log(R1) - R1 ** 3 * np.log(R2))
-    beta = -3 * gam * (np.log(R2) - np.log(R1)) / (R1 ** 3 * np.log(R2) - R2 ** 3 * np.log(R1))
-    fr = alpha / r ** 2 + beta * r
-    gr = -2.0 / r ** 2 * (alpha * np.log(r) + beta / 3.0 * r ** 3 + gam)
+    if m == -1:
+        fr = alpha / r ** 2 + beta * r
+        gr = -2.0 / r ** 2 * (alpha * np.log(r) + beta / 3.0 * r ** 3 + gam)
+        hr = 2.0 / r * gr
+    else:
+        fr = alpha / r ** (m + 3) + beta * r
+        gr = -2.0 / r ** 2 * (-alpha / (m + 1) * r ** (-m - 1) + beta / 3.0 * r ** 3 + gam)
+        hr = (m + 3) / r * gr * r ** (m + 1)
     vr, vt, vp = gr * np.cos(theta), fr * np.sin(theta), fr * np.sin(theta)
     st, ct, sp, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
     v = np.stack([st * cp * vr + ct * cp * vt - sp * vp, st * sp * vr + ct * sp * vt + cp * vp, ct * vr - st * vt], axis=1)
-    p = 2.0 / r * gr * np.cos(theta) + 1000.0 * (R2 - r)
+    p = hr * np.cos(theta) + 1000.0 * (R2 - r)
     return v, p
 
 
@@ -901,4 +915,39 @@ def hollow_sphere(refinement=1, tol=1e-8, n_cheap=200):
         pressure_scaling=1.0 / (1e4 / (6336000.0 - 3481000.0) * (R2 - R1)), tol=tol, n_cheap=n_cheap, n_expensive=1000,
         initial_pressure=lambda x: 1000.0 * (R2 - np.linalg.norm(x, axis=1)),
         boundary_velocity=lambda x: hollow_sphere_solution(x)[0],
+        make_hierarchy=lambda r, only_finest: sm.ShellHierarchy(r, R1, R2, zero_velocity=True, only_finest=only_finest, n_coarse=12))
+
+
+def hollow_sphere_project_q1(refinement=1):
+    """tests/hollow_sphere_gmg_project_q1.prm: the hollow-sphere benchmark with its default viscosity parameter m = 3
+    (mu = r^4, density hollow_sphere.cc:386-390) under `Material averaging = project to Q1 only viscosity` (the density stays
+    at the quadrature points), tolerance 1e-8, 100 cheap steps, on the mesh of `hollow_sphere`."""
+    from . import shellmesh as sm
+    m = 3
+    R1, R2, gam, alpha, beta = _hollow_sphere_constants(m)
+
+    def density(x):
+        r = np.linalg.norm(x, axis=1)
+        ct = x[:, 2] / r
+        return -(2 * alpha * r ** -4 * (m + 3) / (m + 1) * (m - 1) - 2 * beta / 3 * (m - 1) * (m + 3) * r ** m
+                 - m * (m + 5) * 2 * gam * r ** (m - 3)) * ct + 1000.0
+
+    def force_q(level):
+        xq = level.qpoint_coords()
+        flat = xq.reshape(-1, 3)
+        rhat = flat / np.linalg.norm(flat, axis=1, keepdims=True)
+        return (-density(flat)[:, None] * rhat).reshape(xq.shape)
+
+    def scaling(level):      # exp(mean log eta at the cell midpoints) / length scale (helper_functions.cc:252-320)
+        xm = level.qpoint_coords()[:, 13, :]
+        w = level.jxw[:, 13]
+        eta_ref = np.exp((np.log(np.linalg.norm(xm, axis=1) ** (m + 1)) * w).sum() / w.sum())
+        return float(eta_ref) / (1e4 / (6336000.0 - 3481000.0) * (R2 - R1))
+
+    return StokesProblem(
+        name=f"hollow_sphere_project_q1_r{refinement}", dim=3, refinement=refinement, bc=None,
+        eta=lambda x: np.linalg.norm(x, axis=1) ** (m + 1), force=None, force_q=force_q, averaging=bm.AVG_PROJECT_Q1,
+        pressure_scaling=1.0, pressure_scaling_from_mesh=scaling, tol=1e-8, n_cheap=100, n_expensive=1000,
+        initial_pressure=lambda x: 1000.0 * (R2 - np.linalg.norm(x, axis=1)),
+        boundary_velocity=lambda x: hollow_sphere_solution(x, m)[0],
         make_hierarchy=lambda r, only_finest: sm.ShellHierarchy(r, R1, R2, zero_velocity=True, only_finest=only_finest, n_coarse=12))

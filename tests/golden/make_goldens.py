@@ -19,7 +19,7 @@ CASES = ["sol_cx_2_gmg", "sol_cx_4_gmg", "sol_cx_4_gmg_no_avg", "no_cheap_gmg", 
          "nonlinear_channel_flow_velocities_Newton_Stokes_GMG",
          "tosi_benchmark_gmg_newton_solver", "tosi_benchmark_gmg_dc_picard_solver", "tangurnis_tala_gmg", "gmg_mesh_deform_prescribed", "crameri_benchmark_1_gmg", "free_surface_iterated_stokes_gmg",
          "solver_scheme_no_advection_single_stokes", "gmg_mesh_deform_topo", "convection_box_phase_function"]
-SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg"]
+SHELL_CASES = ["hollow_sphere_gmg", "spherical_nsinker_gmg_gc", "shell_3d_gmg", "hollow_sphere_gmg_project_q1"]
 
 
 def parse(path):

@@ -204,7 +204,7 @@ def relative_residual_second_iteration(solver, p, x1, rep1):
     return rep2.initial_nonlinear_residual / r0, rep2
 
 
-def hollow_sphere_errors(p, x):
+def hollow_sphere_errors(p, x, m=-1):
     """u_L1, p_L1, u_L2, p_L2 of benchmarks/hollow_sphere/hollow_sphere.cc:513-556 (QGauss(4) per
     direction under the degree-4 mapping, cell-wise errors stored as float) and the relative residual
     bookkeeping needs: x is the solve's solution (constrained entries zero); the finite element
@@ -228,7 +228,7 @@ def hollow_sphere_errors(p, x):
     xq, jxw = fin.mapped_quadrature(gx, gw)
     uq = np.einsum("qi,cid->cqd", S2, u[fin.cell_nodes_v.astype(np.int64)])
     pq = np.einsum("qi,ci->cq", S1, pr[fin.cell_nodes_p.astype(np.int64)])
-    ua, pa = cases.hollow_sphere_solution(xq.reshape(-1, 3))
+    ua, pa = cases.hollow_sphere_solution(xq.reshape(-1, 3), m)
     du, dp = uq - ua.reshape(uq.shape), pq - pa.reshape(pq.shape)
     f32, f64 = np.float32, np.float64
     e_u1 = (np.abs(du).sum(axis=2) * jxw).sum(axis=1).astype(f32).astype(f64)

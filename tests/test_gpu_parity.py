@@ -950,3 +950,11 @@ def test_convection_box_phase_function_first_solve_golden(hip_lib):
     x, rep, rc = s.solve()
     s.close()
     assert rc == 0 and (rep.n_cheap_iterations, rep.n_expensive_iterations) == (GOLD["convection_box_phase_function"]["solves"][0]["cheap"], 0)
+
+
+def test_hollow_sphere_project_q1_golden(hip_lib):
+    """tests/hollow_sphere_gmg_project_q1 (viscosity r^4 projected to Q1 per cell, per-q tables on every level of the
+    shell) through the HIP library: the checks of the oracle test."""
+    from test_oracle_goldens import _solve_hollow_sphere, check_hollow_sphere
+    check_hollow_sphere(*_solve_hollow_sphere(lambda p: capi.Solver(hip_lib, p), "hollow_sphere_project_q1"),
+                        golden="hollow_sphere_gmg_project_q1", m=3)
