@@ -298,7 +298,7 @@ def main():
     # ---------------------------------------------------------------- configs[2]: nsinker, 8 sinkers, ratio 1e6, r6
     config3 = None
     if args.config3_refinement and rank == 0 and world == 1:
-        p3 = cases.nsinker_box(args.config3_refinement).build()
+        p3 = cases.nsinker_box(args.config3_refinement, average_density=True).build()
         s3 = capi.Solver(lib, p3, device=local_rank)
         x3, r3a, rc3 = s3.solve(allow_failure=True)
         x3, r3b, rc3 = s3.solve(allow_failure=True)
@@ -307,7 +307,7 @@ def main():
                                f"{p3.hier.finest.n_cells} cells, {p3.hier.finest.n_dofs_v}+{p3.hier.finest.n_dofs_p} DoFs",
                    "gmres_iterations": f"{r3b.n_cheap_iterations}+{r3b.n_expensive_iterations}", "solve_status": rc3,
                    "solve_seconds": r3b.solve_seconds, "solve_seconds_including_smoother_setup": r3b.solve_seconds + t3["smoother_setup"],
-                   "oracle_iterations_r2_r3_r4": "36, 48, 74 (identical on the GPU; profiles/r2_config3_nsinker_iterations.jsonl)"}
+                   "oracle_iterations_r2_r3_r4": "35, 46, 72 (identical on the GPU; profiles/r2_config3_nsinker_iterations.jsonl)"}
         s3.close()
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE configs[2] (benchmarks/nsinker: 8 sinkers, viscosity ratio 1e6, harmonic average of the
-viscosity only, tolerance 1e-6, GMRES(100), 200 cheap steps): GMRES iteration counts and solve times
+"""BASELINE configs[2] (benchmarks/nsinker: 8 sinkers, viscosity ratio 1e6, harmonic average of
+viscosity and density as its deck asks, tolerance 1e-6, GMRES(100), 200 cheap steps): GMRES iteration counts and solve times
 of the HIP library up to r = 6 beside the CPU oracle's up to the refinement it solves in about a minute.
     python tools/config3_iterations.py [max_gpu_r] [max_oracle_r]"""
 import json
@@ -16,7 +16,7 @@ max_gpu = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 max_ora = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = []
 for r in range(2, max_gpu + 1):
-    p = cases.nsinker_box(r).build()
+    p = cases.nsinker_box(r, average_density=True).build()
     g = capi.Solver(capi.load(), p)
     x, rep, rc = g.solve(allow_failure=True)
     x, rep2, rc2 = g.solve(allow_failure=True)       # second solve: smoothers cached
