@@ -253,6 +253,76 @@ __global__ void __launch_bounds__(256) k_restrict_cells(const RestrArgs A) {
   for (int a = 0; a < NLOC; ++a) A.slots[((size_t)a * A.cstride_c + cell) * NC + c] = acc[a];
 }
 
+// The same restriction with the (2K+1) planes of a parent's patch on separate lanes: lane = (parent cell, component, plane
+// r2).  A lane gathers its plane (one index load and one value pair per fine node, all independent) and reduces it to the
+// (K+1)^2 in-plane sums; the (K+1) lanes with r2 <= K then combine the planes through LDS, in the plane order of
+// k_restrict_cells (bit-identical).  The one-lane form walks the planes one after the other: 2 x (2K+1) dependent gathers,
+// 21 us on levels of 6 to 48 workgroups.  3-D only (the 2-D patch is one plane).
+template <int K, int NC>
+__global__ void __launch_bounds__(256) k_restrict_planes(const RestrArgs A) {
+  constexpr int N1 = K + 1, NF = 2 * K + 1, NPL = N1 * N1;
+  constexpr int GROUPS = 256 / NF;                       // (cell, component) pairs per workgroup
+  __shared__ double sh[GROUPS][NF][NPL];
+  const int grp = threadIdx.x / NF, r2 = threadIdx.x - grp * NF;
+  const long t = (long)blockIdx.x * GROUPS + grp;
+  const bool live = grp < GROUPS && t < (long)A.n_coarse_cells * NC;
+  const int cell = live ? (int)(t / NC) : 0, c = live ? (int)(t - (long)cell * NC) : 0;
+  if (live) {
+    const int up2 = r2 > K ? 1 : 0;
+    uint32_t ch[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ch[k] = A.childrenT[(size_t)(k + 4 * up2) * A.cstride_c + cell];
+    uint32_t fn[NF][NF];
+#pragma unroll
+    for (int r1 = 0; r1 < NF; ++r1)
+#pragma unroll
+      for (int r0 = 0; r0 < NF; ++r0) {
+        const int up0 = r0 > K ? 1 : 0, up1 = r1 > K ? 1 : 0;
+        const int loc = (r0 - K * up0) + N1 * (r1 - K * up1) + N1 * N1 * (r2 - K * up2);
+        fn[r1][r0] = A.cnfT[(size_t)loc * A.cstride_f + ch[up0 | (up1 << 1)]] & NODE_MASK;
+      }
+    double v[NF][NF];
+#pragma unroll
+    for (int r1 = 0; r1 < NF; ++r1)
+#pragma unroll
+      for (int r0 = 0; r0 < NF; ++r0) v[r1][r0] = A.inv_mult[fn[r1][r0]] * A.src[(size_t)fn[r1][r0] * NC + c];
+    double tx[NF][N1];
+#pragma unroll
+    for (int r1 = 0; r1 < NF; ++r1)
+#pragma unroll
+      for (int i0 = 0; i0 < N1; ++i0) {
+        double s = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < NF; ++r0)
+          if (pw<K>(r0, i0) != 0.0) s = fma(pw<K>(r0, i0), v[r1][r0], s);
+        tx[r1][i0] = s;
+      }
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+      for (int i0 = 0; i0 < N1; ++i0) {
+        double s = 0.0;
+#pragma unroll
+        for (int r1 = 0; r1 < NF; ++r1)
+          if (pw<K>(r1, i1) != 0.0) s = fma(pw<K>(r1, i1), tx[r1][i0], s);
+        sh[grp][r2][i0 + N1 * i1] = s;
+      }
+  }
+  __syncthreads();
+  if (live && r2 < N1) {
+    const int i2 = r2;
+#pragma unroll
+    for (int a = 0; a < NPL; ++a) {
+      double acc = 0.0;
+      for (int q = 0; q < NF; ++q) {
+        const double w = prow<K>(q, i2);
+        if (w != 0.0) acc = fma(w, sh[grp][q][a], acc);
+      }
+      A.slots[((size_t)(a + NPL * i2) * A.cstride_c + cell) * NC + c] = acc;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLevel &coarse, bool velocity,
@@ -319,6 +389,17 @@ int launch_restrict_cells(hipStream_t s, const DeviceLevel &fine, const DeviceLe
   const long n = (long)coarse.n_cells * (velocity ? fine.dim : 1);
   if (n <= 0) return 0;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  // velocity patches in 3-D on levels that do not fill the chip: one lane per plane of the patch
+  // (AGMG_RESTRICT_PLANES_MAX: developer/test knob for the switch-over size, read per call)
+  const char *env = getenv("AGMG_RESTRICT_PLANES_MAX");
+  const long planes_max = env ? atol(env) : 32768;
+  if (fine.dim == 3 && velocity && coarse.n_cells <= planes_max) {
+    constexpr int GROUPS = 256 / 5;
+    const dim3 g2((unsigned)((n + GROUPS - 1) / GROUPS));
+    hipLaunchKernelGGL((k_restrict_planes<2, 3>), g2, block, 0, s, a);
+    AGMG_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (fine.dim == 3) {
     if (velocity) hipLaunchKernelGGL((k_restrict_cells<3, 2, 3>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_restrict_cells<3, 1, 1>), grid, block, 0, s, a);

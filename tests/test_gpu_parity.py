@@ -958,3 +958,19 @@ def test_hollow_sphere_project_q1_golden(hip_lib):
     from test_oracle_goldens import _solve_hollow_sphere, check_hollow_sphere
     check_hollow_sphere(*_solve_hollow_sphere(lambda p: capi.Solver(hip_lib, p), "hollow_sphere_project_q1"),
                         golden="hollow_sphere_gmg_project_q1", m=3)
+
+
+@pytest.mark.parametrize("name", ["nsinker_r2_perq", "deformed3d_r3_perq", "box3d_r3_freeslip"])
+def test_plane_per_lane_restriction_is_bit_identical(name, hip_lib, monkeypatch):
+    """k_restrict_planes (one lane per plane of a parent's 5 x 5 x 5 patch, planes combined through LDS in the order of
+    k_restrict_cells) against the one-lane-per-parent form (AGMG_RESTRICT_PLANES_MAX=0): the same V-cycle bit for bit."""
+    p = PROBLEMS[name]().build()
+    s = capi.Solver(hip_lib, p)
+    s.setup_smoothers()
+    src = rand_vec(s.size(capi.OP_A), 6, p.hier.finest)
+    monkeypatch.setenv("AGMG_RESTRICT_PLANES_MAX", "0")
+    va = s.vcycle(capi.OP_A, src)
+    monkeypatch.delenv("AGMG_RESTRICT_PLANES_MAX")
+    vb = s.vcycle(capi.OP_A, src)
+    s.close()
+    assert np.array_equal(va, vb)
