@@ -308,7 +308,7 @@ struct agmg_ctx {
   void free_level(DeviceLevel &l);
   void free_coeff(CoeffData &cd) {
     dfree(cd.etaT); dfree(cd.nw_strain); dfree(cd.nw_dEde); dfree(cd.nw_dEdp);
-    dfree(cd.dil_lhs); dfree(cd.dil_de); dfree(cd.dil_dp); dfree(cd.ell_val);
+    dfree(cd.dil_lhs); dfree(cd.dil_de); dfree(cd.dil_dp); dfree(cd.ell_val); dfree(cd.brick_geo);
     cd = CoeffData();
   }
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
@@ -387,7 +387,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.bk.gnode); dfree(l.bk.bcell); dfree(l.bk.pidx); dfree(l.bk.fx_nodes); dfree(l.bk.fx_ptr); dfree(l.bk.fx_list);
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.gid_v); dfree(l.gid_p);
-  dfree(l.ell_col); dfree(l.coeff.ell_val);
+  dfree(l.ell_col); dfree(l.coeff.ell_val); dfree(l.coeff.brick_geo);
   l = DeviceLevel();
 }
 
@@ -2483,6 +2483,13 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   }
   cd.set = true;
   c->diag_ready = false; c->smoothers_ready = false;
+  // brick levels: viscosity rows and cell extents in brick order (kernels_brickq.hip)
+  c->dfree(cd.brick_geo);
+  if (lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && c->use_bricks && !c->dist()) {
+    CHECK(c->dalloc(&cd.brick_geo, brick_geo_doubles(lv, cd.nqv)));
+    CHECK(launch_brick_geo(c->stream, lv, cd));
+    cd.bytes += brick_geo_doubles(lv, cd.nqv) * 8;
+  }
   // assembled rows of the mass operator with these coefficients (MassMatrixOperator of this level)
   if (cd.ell_stride != lv.ell_stride) { c->dfree(cd.ell_val); cd.ell_stride = 0; }
   // (not for the active-mesh coefficients: the solve only applies the level operators' mass

@@ -70,6 +70,9 @@ struct CoeffData {     // OperatorCellData of one level (or of the active mesh)
   double *dil_lhs = nullptr, *dil_de = nullptr, *dil_dp = nullptr;
   double *ell_val = nullptr;   // assembled mass rows [ell_w][ell_stride] of the level these coefficients belong to
   int ell_stride = 0;          // 0: not assembled
+  // brick levels (kernels_brickq.hip): the viscosity rows and the cell extents in brick order,
+  // [brick][layer][nqv + 3][64]; nullptr: not built (general geometry, no brick tables)
+  double *brick_geo = nullptr;
   size_t bytes = 0;
 };
 
@@ -266,6 +269,12 @@ int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const u
 // to `partials` (3 * n_partial_slots doubles).  ep (Stokes): also finish the pressure rows.
 int launch_op_bricks(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
                      const double *src_p, double *partials, double *slots_p, const EpiArgs &eu, const EpiArgs *ep);
+// quad-per-cell brick kernels (kernels_brickq.hip): main kernel only, the fix-up is launch_op_bricks'
+bool brickq_supported(const DeviceLevel &L, const CoeffData &cd, int which);
+size_t brick_geo_doubles(const DeviceLevel &L, int nqv);
+int launch_brick_geo(hipStream_t s, const DeviceLevel &L, const CoeffData &cd);
+int launch_brickq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u, const double *src_p,
+                  double *partials, double *slots_p, const EpiArgs &eu);
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,
               int phase = PH_ALL, const EpiArgs *ep = nullptr);

@@ -28,6 +28,7 @@
 #include "kernels_cell.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace agmg {
@@ -452,7 +453,11 @@ int launch_op_bricks(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, i
   const BrickArgs b{bk.gnode, bk.bcell, bk.pidx, partials, bk.Z, bk.latn, bk.npb, dbg_buf};
   const bool perq = cd.nqv > 1;
   const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;
-  if (L.geom == AGMG_GEOM_GENERAL) launch_brick_op<true>(s, a, b, eu, bk.n_bricks, which, comp, perq);
+  static const bool use_q = !(getenv("AGMG_BRICKQ") && atoi(getenv("AGMG_BRICKQ")) == 0);
+  if (use_q && brickq_supported(L, cd, which)) {
+    const int rc = launch_brickq(s, L, cd, which, src_u, src_p, partials, slots_p, eu);
+    if (rc) return rc;
+  } else if (L.geom == AGMG_GEOM_GENERAL) launch_brick_op<true>(s, a, b, eu, bk.n_bricks, which, comp, perq);
   else launch_brick_op<false>(s, a, b, eu, bk.n_bricks, which, comp, perq);
   AGMG_HIP_CHECK(hipGetLastError());
 #if AGMG_ABLATE & 2048
