@@ -314,11 +314,13 @@ struct agmg_ctx {
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                          const std::vector<uint32_t> &send_nodes);
   int build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv);
-  // brick kernels on structured 3-D levels: parity-green but not yet faster than the block kernels
-  // (DESIGN.md 3.2b), so opt-in: AGMG_BRICKS=1
-  bool use_bricks = false;
+  // quad-per-cell brick kernel (kernels_brickq.hip) for the A block of structured Cartesian 3-D levels: faster than
+  // the block kernels from 512 cubes of 8^3 cells on (r6: 121 -> 99 us, r7: 891 -> 776 us), slower below (r5: 23.3 ->
+  // 24.5 us), so by default only those levels get brick tables.  AGMG_BRICKS=1: every level that tiles into
+  // cubes; AGMG_BRICKS=0: none.
+  int use_bricks = 2;       // 0 off, 1 every level that qualifies, 2 large levels only
   int brick_z_override = 0; // AGMG_BRICK_Z: layers per brick (1, 2, 4 or 8) instead of the size-based choice
-  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && !dist(); }
+  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && !dist(); }
   int ensure_workspace();
   int ensure_transfers();
   int ensure_mg_vectors();
@@ -338,7 +340,7 @@ struct agmg_ctx {
   int op_velocity(const DeviceLevel &lv, const CoeffData &cd, int which, const double *src_u, const double *src_p,
                   const EpiArgs &eu, const EpiArgs *ep = nullptr) {
     const bool epi_ok = eu.epi == EPI_STORE || eu.epi == EPI_RESID || eu.epi == EPI_CHEB;
-    if (bricks_on(lv) && epi_ok && !((cd.newton || cd.dilation) && which == AGMG_OP_STOKES))
+    if (bricks_on(lv) && epi_ok && brickq_supported(lv, cd, which))
       return launch_op_bricks(stream, lv, cd, which, src_u, src_p, slots_u, slots_p, eu, ep);
     return launch_op(stream, lv, cd, which, src_u, src_p, slots_u, slots_p, eu, use_blocks, PH_ALL, ep);
   }
@@ -560,6 +562,8 @@ int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std
   BrickTables &bk = lv.bk;
   const int n = lv.n_cells, nn = lv.n_nodes_v;
   if (lv.dim != 3 || n < 512 || n % 512 != 0 || (unsigned)nn > BRICK_NODE_MASK || dist()) return 0;
+  if (lv.geom != AGMG_GEOM_CARTESIAN) return 0;                 // (the brick kernel reads cell extents)
+  if (use_bricks == 2 && n < 512 * 512) return 0;               // small levels: the block kernels are faster
   const uint32_t *cnv = hl.cnv.data();
   // face centres: local nodes (0,1,1) (2,1,1) (1,0,1) (1,2,1) (1,1,0) (1,1,2)
   static const int FC[6] = {12, 14, 10, 16, 4, 22};
@@ -2082,7 +2086,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   auto *c = new agmg_ctx();
   c->opt = *opt;
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
-  if (const char *e = getenv("AGMG_BRICKS")) c->use_bricks = atoi(e) != 0;
+  if (const char *e = getenv("AGMG_BRICKS")) c->use_bricks = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("AGMG_BRICK_Z")) c->brick_z_override = atoi(e);
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;

@@ -86,12 +86,13 @@ template <int OP, bool COMP, bool PERQ>
 __global__ void __launch_bounds__(BQ_T, 2)
 k_brickq(const BqArgs B, const EpiArgs E) {
   constexpr int NQ = PERQ ? 27 : 1;
-  constexpr int ROWS = NQ + 3;
+  constexpr int ROWS = NQ + 4;
   constexpr int GEO_D = ROWS * 64 > BQ_FACE_D ? ROWS * 64 : BQ_FACE_D;   // also hosts the y-face tile
   constexpr int GEO_PT = (ROWS * 32 + BQ_T - 1) / BQ_T;                  // double2 pieces per thread
   __shared__ double src_t[3 * BQ_PLANE_D];
   __shared__ __attribute__((aligned(16))) double geo_t[GEO_D];
-  __shared__ double tile[BQ_OUT_D];
+  __shared__ double tile[BQ_OUT_D];      // a_x = 2 faces / the parked carry
+  __shared__ double out_t[BQ_OUT_D];     // finished planes [plane][node][component]
   __shared__ uint32_t wring[BQ_WRING * BRICK_PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = lane >> 2, cq = lane & 3;
@@ -233,9 +234,10 @@ k_brickq(const BqArgs B, const EpiArgs E) {
         }
     }
     // geometry and coefficients of this lane's cell, in the rotated frame
-    double hl[3];
+    double ih[3];    // 1 / (Gauss point spacing * cell extent) along the local axes
 #pragma unroll
-    for (int r = 0; r < 3; ++r) hl[r] = geo_t[(NQ + gax[r]) * 64 + cl];
+    for (int r = 0; r < 3; ++r) ih[r] = geo_t[(NQ + gax[r]) * 64 + cl];
+    const double det = geo_t[(NQ + 3) * 64 + cl];
     const double eta_c = PERQ ? 1.0 : geo_t[cl];
     int es[3];   // stride of the viscosity tile along local axis r
 #pragma unroll
@@ -250,10 +252,6 @@ k_brickq(const BqArgs B, const EpiArgs E) {
     // ---- cell operation (rotated frame)
     double G[27];
     {
-      const double det = hl[0] * hl[1] * hl[2];
-      double ih[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) ih[r] = INV_S / hl[r];
       const double ce = det * eta_c;
       // flux along local axis r:  f * (P[r] * dref_r u_c + Q[r] * dref_c u_{c+r})   (r = 0: both are the same)
       const double P0 = 2.0 * ce * ih[0] * ih[0], P1 = ce * ih[1] * ih[1], P2 = ce * ih[2] * ih[2];
@@ -278,7 +276,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
         if (p1 < p || p2 < p) continue;          // orbits are entered at their smallest point
         const int n = p1 == p ? 1 : 3;
         const int pts[3] = {p, p1, p2};
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);   // (orbit by orbit: keeps the register pressure of the unrolled loop down)
         double D0[3], D1[3], D2[3], et[3];
 #pragma unroll
         for (int t = 0; t < n; ++t) {
@@ -344,11 +342,17 @@ k_brickq(const BqArgs B, const EpiArgs E) {
     }
 #pragma unroll
     for (int m = 0; m < 9; ++m) carry[m] = my_face[m * 192];
-    // ---- sums over the cells of the layer that share a node: the a_x = 2 face goes to cell + 1, then the
-    // a_y = 2 face (with what it just received) to cell + 8
+    // ---- sums over the cells of the layer that share a node, owner by owner: a lane owns the nodes a_x, a_y < 2
+    // of its cell (the upper ring too at i = 7 / j = 7).  Every lane publishes its a_x = 2 face and its a_y = 2
+    // face; an owner adds, in this order, the left cell's (2, a_y), the lower cell's (a_x, 2) and the diagonal
+    // cell's (2, 2).  (Sums of nodes a lane does not own pick up stray terms and are never stored.)
     if (live) {
 #pragma unroll
-      for (int m = 0; m < 9; ++m) my_face[m * 192] = Gg[2 + 3 * m];
+      for (int m = 0; m < 9; ++m) my_face[m * 192] = Gg[2 + 3 * m];              // m = a_y + 3 a_z
+#pragma unroll
+      for (int az = 0; az < 3; ++az)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) my_yface[(az * 3 + ax) * 192] = Gg[ax + 6 + 9 * az];
     }
     __syncthreads();
     BQ_STAMP(3);
@@ -356,19 +360,15 @@ k_brickq(const BqArgs B, const EpiArgs E) {
 #pragma unroll
       for (int m = 0; m < 9; ++m) Gg[3 * m] += my_face[m * 192 - 3];
     }
-    if (live) {
-#pragma unroll
-      for (int az = 0; az < 3; ++az)
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) my_yface[(az * 3 + ax) * 192] = Gg[ax + 6 + 9 * az];
-    }
-    __syncthreads();
-    BQ_STAMP(4);
     if (jj > 0) {
 #pragma unroll
       for (int az = 0; az < 3; ++az)
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) Gg[ax + 9 * az] += my_yface[(az * 3 + ax) * 192 - 24];
+    }
+    if (ii > 0 && jj > 0) {
+#pragma unroll
+      for (int az = 0; az < 3; ++az) Gg[9 * az] += my_face[(2 + 3 * az) * 192 - 27];
     }
     // the lower plane is complete with the previous layer's upper plane; the upper plane waits
 #pragma unroll
@@ -376,6 +376,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
       Gg[m] += carry[m];
       carry[m] = Gg[18 + m];
     }
+    BQ_STAMP(4);
     // finished planes -> out tile [plane][node][component]: the lane owns a_x, a_y < 2 (the upper ring too
     // for the lanes at i = 7 / j = 7)
     if (live) {
@@ -386,7 +387,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax)
             if ((ax < 2 || ii == 7) && (ay < 2 || jj == 7))
-              tile[(az * BRICK_PLANE + (2 * jj + ay) * BRICK_LAT + 2 * ii + ax) * 3 + c] = Gg[ax + 3 * ay + 9 * az];
+              out_t[(az * BRICK_PLANE + (2 * jj + ay) * BRICK_LAT + 2 * ii + ax) * 3 + c] = Gg[ax + 3 * ay + 9 * az];
     }
     __syncthreads();
     BQ_STAMP(5);
@@ -408,7 +409,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
         const int K = 2 * k + pl;
         w[m] = wring[(K % BQ_WRING) * BRICK_PLANE + r];
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) v[m][cc] = tile[nn * 3 + cc];
+        for (int cc = 0; cc < 3; ++cc) v[m][cc] = out_t[nn * 3 + cc];
         any_con = any_con || ((w[m] >> 29) != 0 && !(w[m] & BRICK_PARTIAL));
       }
       // destination: the row itself, or this brick's partial-sum slot of a row another brick owns
@@ -482,7 +483,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax)
         if ((ax < 2 || ii == 7) && (ay < 2 || jj == 7))
-          tile[((2 * jj + ay) * BRICK_LAT + 2 * ii + ax) * 3 + c] = carry[ax + 3 * ay];
+          out_t[((2 * jj + ay) * BRICK_LAT + 2 * ii + ax) * 3 + c] = carry[ax + 3 * ay];
   }
   __syncthreads();
   {
@@ -499,7 +500,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
           const bool con = (w >> (29 + cc)) & 1u;
-          const double val = tile[n * 3 + cc];
+          const double val = out_t[n * 3 + cc];
           double o = val;
           if (fin) {
             const double xvv = (E.epi == EPI_CHEB || (con && E.x)) ? E.x[t + cc] : 0.0;
@@ -518,20 +519,24 @@ k_brickq(const BqArgs B, const EpiArgs E) {
   }
 }
 
-// coefficient rows in brick order: geo[brick][layer][row][lane] = viscosity rows of the layer's cells, then their
-// three extents (MappingCartesian)
+// coefficient rows in brick order: geo[brick][layer][row][lane] = viscosity rows of the layer's cells, then
+// 1 / (Gauss point spacing * extent) along x, y, z and the cell volume (MappingCartesian)
 __global__ void __launch_bounds__(256) k_brick_geo(double *__restrict__ geo, const uint32_t *__restrict__ bcell,
                                                    const double *__restrict__ etaT, const double *__restrict__ hT,
                                                    const int nq, const size_t cs, const size_t n_layers) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int rows = nq + 3;
+  const int rows = nq + 4;
   if (t >= n_layers * rows * 64) return;
   const int ln = (int)(t & 63);
   const size_t lr = t >> 6;
   const size_t layer = lr / rows;
   const int row = (int)(lr - layer * rows);
   const uint32_t cell = bcell[layer * 64 + ln];
-  geo[t] = row < nq ? etaT[(size_t)row * cs + cell] : hT[(size_t)(row - nq) * cs + cell];
+  double v;
+  if (row < nq) v = etaT[(size_t)row * cs + cell];
+  else if (row < nq + 3) v = INV_S / hT[(size_t)(row - nq) * cs + cell];
+  else v = hT[cell] * hT[cs + cell] * hT[2 * cs + cell];
+  geo[t] = v;
 }
 
 }  // namespace
@@ -541,12 +546,12 @@ bool brickq_supported(const DeviceLevel &L, const CoeffData &cd, int which) {
          !cd.newton;
 }
 
-size_t brick_geo_doubles(const DeviceLevel &L, int nqv) { return (size_t)L.bk.n_bricks * L.bk.Z * (nqv + 3) * 64; }
+size_t brick_geo_doubles(const DeviceLevel &L, int nqv) { return (size_t)L.bk.n_bricks * L.bk.Z * (nqv + 4) * 64; }
 
 int launch_brick_geo(hipStream_t s, const DeviceLevel &L, const CoeffData &cd) {
   if (!L.bk.built || !cd.brick_geo || !cd.etaT || !L.cell_hT) { set_error("brick coefficient rows: tables missing"); return -4; }
   const size_t n_layers = (size_t)L.bk.n_bricks * L.bk.Z;
-  const size_t n = n_layers * (cd.nqv + 3) * 64;
+  const size_t n = n_layers * (cd.nqv + 4) * 64;
   hipLaunchKernelGGL(k_brick_geo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cd.brick_geo, L.bk.bcell, cd.etaT, L.cell_hT,
                      cd.nqv, (size_t)L.cstride, n_layers);
   AGMG_HIP_CHECK(hipGetLastError());
@@ -563,7 +568,7 @@ int launch_brickq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int 
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)1 << 26);
 #endif
   const BqArgs b{dbg_buf, bk.gnode, bk.bcell, cd.brick_geo, src_u, src_p, L.cnpT, partials, slots_p, cd.lambda,
-                 bk.Z, bk.latn, bk.npb, cd.nqv + 3, L.cstride};
+                 bk.Z, bk.latn, bk.npb, cd.nqv + 4, L.cstride};
   const dim3 grid(bk.n_bricks), block(BQ_T);
   if (comp) {
     if (perq) hipLaunchKernelGGL((k_brickq<KOP_A, true, true>), grid, block, 0, s, b, eu);
