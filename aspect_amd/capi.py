@@ -148,6 +148,8 @@ class Library:
         self.vmult_device = fn("vmult_device", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
         self.vmult_device_noalloc = fn("vmult_device_noalloc", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
         self.vmult_dense = fn("vmult_dense", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
+        # (checker library only: the CPU baseline leg of bench.py, SIMD across cells; returns the lanes used)
+        self.vmult_simd = fn("vmult_simd", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp]) if "vmult_simd" in optional or prefix != "agmg_" else None
         self.get_inverse_diagonal = fn("get_inverse_diagonal", C.c_int, [vp, C.c_int, C.c_int, c_dp])
         self.prolongate_add = fn("prolongate_add", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         self.restrict_add = fn("restrict_add", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
@@ -185,7 +187,7 @@ def load():
     """Load the product HIP library; raises ImportError when it is missing."""
     global _PRODUCT
     if _PRODUCT is None:
-        _PRODUCT = Library(product_library_path(), "agmg_", optional=("vmult_dense",))
+        _PRODUCT = Library(product_library_path(), "agmg_", optional=("vmult_dense", "vmult_simd"))
     return _PRODUCT
 
 
@@ -352,6 +354,15 @@ class Solver:
         f = self.lib.vmult_dense if dense else self.lib.vmult
         self._check(f(self.ctx, which, level, _ptr(dst, C.c_double), _ptr(src, C.c_double)))
         return dst
+
+    def vmult_simd(self, which, src, level=ACTIVE):
+        """Checker library only (oracle/cpu_simd.cpp): the operator with SIMD across cells; returns (dst, lanes)."""
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        dst = np.zeros_like(src)
+        lanes = self.lib.vmult_simd(self.ctx, which, level, _ptr(dst, C.c_double), _ptr(src, C.c_double))
+        if lanes < 0:
+            raise RuntimeError("vmult_simd does not cover this level")
+        return dst, lanes
 
     def rhs_correction(self, u0, rhs):
         """correct_stokes_rhs(): rhs - M u0 with u0 read without the constraints."""

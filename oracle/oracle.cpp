@@ -1659,6 +1659,58 @@ int oracle_rhs_correction(oracle_ctx *o, const double *u0, double *rhs) {
 int oracle_vmult(oracle_ctx *o, int which, int level, double *dst, const double *src) { vmult_impl(o->c, which, level, dst, src, false); return 0; }
 int oracle_vmult_dense(oracle_ctx *o, int which, int level, double *dst, const double *src) { vmult_impl(o->c, which, level, dst, src, true); return 0; }
 
+// ---- CPU baseline leg of bench.py: the same operators with SIMD across cells (oracle/cpu_simd.cpp), OpenMP
+// threads over the cell batches of a colour.  Returns the SIMD lanes used, or -1 if the level is not covered
+// (general geometry, Newton / dilation / face terms, 2-D).
+extern "C" {
+void cpu_simd_cells_v3(int, int, int, const int *, const uint32_t *, const uint32_t *, const uint8_t *, const uint8_t *,
+                       const double *, const double *, int, double, const double *, const double *, double *, double *);
+void cpu_simd_cells_v4(int, int, int, const int *, const uint32_t *, const uint32_t *, const uint8_t *, const uint8_t *,
+                       const double *, const double *, int, double, const double *, const double *, double *, double *);
+}
+int oracle_vmult_simd(oracle_ctx *o, int which, int level, double *dst, const double *src) {
+  Ctx &C = o->c;
+  const Level &L = level == AGMG_ACTIVE ? C.fin() : C.levels[level];
+  const CellData &cd = level == AGMG_ACTIVE ? C.active_cd : L.cd;
+  if (C.opt.dim != 3 || L.geom != AGMG_GEOM_CARTESIAN || cd.newton || cd.dilation || cd.n_faces || which == AGMG_OP_MASS) return -1;
+  const bool wide = __builtin_cpu_supports("avx512f");
+  const int lanes = wide ? 8 : 4;
+  auto kernel = wide ? cpu_simd_cells_v4 : cpu_simd_cells_v3;
+  const int mode = which == AGMG_OP_STOKES ? 0 : (which == AGMG_OP_A ? 1 : 2);
+  const int nu = L.ndv();
+  const double *su = src, *sp = which == AGMG_OP_A ? nullptr : src + nu;
+  double *du = dst, *dp = which == AGMG_OP_A ? nullptr : dst + nu;
+  std::fill(du, du + nu, 0.0);
+  if (dp) std::fill(dp, dp + L.ndp(), 0.0);
+  const auto &colours = cell_colours(L);
+  const int nthreads = oracle_threads();
+  for (const auto &col : colours) {
+    const int n = (int)col.size();
+    const int chunk = std::max(lanes, ((n + 8 * nthreads - 1) / (8 * nthreads) + lanes - 1) / lanes * lanes);
+    const int n_chunks = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      const int first = ch * chunk, cnt = std::min(chunk, n - first);
+      kernel(mode, cd.is_compressible ? 1 : 0, cnt, col.data() + first, L.cnv.data(), L.cnp.data(), L.cmv.data(), L.cmp.data(),
+             L.cell_h.data(), cd.eta.data(), cd.nqv, cd.lambda, su, sp, du, dp);
+    }
+  }
+  if (which != AGMG_OP_BT)
+    for (int n = 0; n < L.n_nodes_v; ++n)
+      if (L.cmv[n])
+        for (int c = 0; c < 3; ++c)
+          if (L.constrained_v(n, c)) du[size_t(n) * 3 + c] += su[size_t(n) * 3 + c];
+  if (which == AGMG_OP_BT)   // MatrixFreeOperators::Base::vmult on both blocks: identity rows of the velocity block read src_u
+    for (int n = 0; n < L.n_nodes_v; ++n)
+      if (L.cmv[n])
+        for (int c = 0; c < 3; ++c)
+          if (L.constrained_v(n, c)) du[size_t(n) * 3 + c] += su[size_t(n) * 3 + c];
+  if (dp && sp)
+    for (int n = 0; n < L.n_nodes_p; ++n)
+      if (L.constrained_p(n)) dp[n] += sp[n];
+  return lanes;
+}
+
 int oracle_get_inverse_diagonal(oracle_ctx *o, int which, int level, double *dst) {
   const Level &L = o->c.levels[level];
   const Vec &v = which == AGMG_OP_A ? L.inv_diag_A : L.inv_diag_M;

@@ -114,3 +114,27 @@ def test_rank_plumbing_world_size_2_gloo(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_simd_cpu_baseline_matches_the_oracle(oracle_lib):
+    """bench.py's cpu_baseline leg (oracle/cpu_simd.cpp, SIMD across cells) computes the oracle's operators:
+    A, Stokes and B^T on Cartesian 3-D levels with per-q and cell-constant viscosity, compressible too."""
+    import numpy as np
+    from aspect_amd import capi, cases
+    for make, comp in ((lambda: cases.convection_box(3, 2), 0), (lambda: cases.nsinker_box(2, n_sinkers=4, ratio=1e4), 1)):
+        p = make().build()
+        o = capi.Solver(oracle_lib, p)
+        try:
+            if comp:
+                for l in range(p.hier.n_levels):
+                    o._set_coeff(l, p.eta_levels[l], is_compressible=1)
+                o._set_coeff(capi.ACTIVE, p.eta_active, is_compressible=1)
+            rng = np.random.Generator(np.random.PCG64(3))
+            for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT):
+                src = rng.uniform(-1, 1, o.size(which))
+                a = o.vmult(which, src)
+                b, lanes = o.vmult_simd(which, src)
+                assert lanes in (4, 8)
+                assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(a), which
+        finally:
+            o.close()
