@@ -346,6 +346,9 @@ k_brickq(const BqArgs B, const EpiArgs E) {
     // of its cell (the upper ring too at i = 7 / j = 7).  Every lane publishes its a_x = 2 face and its a_y = 2
     // face; an owner adds, in this order, the left cell's (2, a_y), the lower cell's (a_x, 2) and the diagonal
     // cell's (2, 2).  (Sums of nodes a lane does not own pick up stray terms and are never stored.)
+    // (the a_y = 2 faces go where the coefficient rows are: every wavefront must be done with its cell operation,
+    // which reads the viscosity rows to its end)
+    __syncthreads();
     if (live) {
 #pragma unroll
       for (int m = 0; m < 9; ++m) my_face[m * 192] = Gg[2 + 3 * m];              // m = a_y + 3 a_z
