@@ -430,7 +430,9 @@ class Solver:
         return t.value
 
     def solver_timings(self, n_repeat=5):
-        """The reference's 'Execute solver timings' sections, seconds per call."""
+        """Seconds per call of the 'Execute solver timings' sections: the reference's stokes_vmult,
+        stokes_preconditioner, A_preconditioner, S_preconditioner (local_smoothing.cc:1268-1340), then two of this
+        library's own (A_block_vmult, smoother_setup) where the reference times its two cheap solves."""
         out = (C.c_double * 6)()
         self._check(self.lib.execute_solver_timings(self.ctx, n_repeat, out))
         names = ("stokes_vmult", "stokes_preconditioner", "A_preconditioner", "S_preconditioner", "A_block_vmult", "smoother_setup")

@@ -422,7 +422,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
   const int dim = lv.dim, NV = ipow(3, dim), nn = lv.n_nodes_v;
   const int cpw = cells_per_wave(dim), bc = cpw * WAVES_PER_BLOCK;
   const int nb = (lv.n_cells + bc - 1) / bc;
-  // pass 1: the sorted unique nodes of every block; number of blocks touching each node
+  // pass 1: the sorted unique nodes of every block; whether one block or several touch each node
   std::vector<std::vector<uint32_t>> bl_nodes(nb);
   std::vector<uint8_t> nblk(nn, 0);
   parallel_for((size_t)nb, [&](size_t b0, size_t b1, int) {
@@ -432,10 +432,9 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
       u.assign(hl.cnv.begin() + c0 * NV, hl.cnv.begin() + c1 * NV);
       std::sort(u.begin(), u.end());
       u.erase(std::unique(u.begin(), u.end()), u.end());
-      for (uint32_t node : u) {
-        uint8_t &k = nblk[node];
-        if (__atomic_load_n(&k, __ATOMIC_RELAXED) < 255) __atomic_fetch_add(&k, (uint8_t)1, __ATOMIC_RELAXED);
-      }
+      // (only "one block" against "several" is used: bit 0 = seen, bit 1 = seen again; an OR cannot wrap)
+      for (uint32_t node : u)
+        if (__atomic_fetch_or(&nblk[node], (uint8_t)1, __ATOMIC_RELAXED) & 1) __atomic_fetch_or(&nblk[node], (uint8_t)2, __ATOMIC_RELAXED);
     }
   });
   // shared = touched by several blocks; on distributed levels also every ghost node and every owned
@@ -534,6 +533,14 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
       bool ghost = false;
       const int U = (int)blk_hdr[(size_t)b * 4];
       for (int l = 0; l < U && !ghost; ++l) ghost = (int)(unodes[(size_t)b * max_u + l] & NODE_MASK) >= lv.n_owned_v;
+      // (interior blocks of the Stokes and B^T operators read the pressure source before its ghost import has
+      // landed: a block with a ghost pressure node is an interface block too, whatever rule the caller's
+      // partition used for the two spaces)
+      if (!hl.cnp.empty()) {
+        const int NPc = 1 << dim;
+        const size_t c0 = (size_t)b * bc, c1 = std::min(c0 + (size_t)bc, (size_t)lv.n_cells);
+        for (size_t i = c0 * NPc; i < c1 * NPc && !ghost; ++i) ghost = (int)hl.cnp[i] >= lv.n_owned_p;
+      }
       (ghost ? iface : order).push_back((uint32_t)b);
     }
     bt.n_interior = (int)order.size();
@@ -2702,10 +2709,16 @@ int agmg_vmult_device_noalloc(agmg_ctx *c, int which, int level, double *dst, co
   const DeviceLevel &lv = c->L[l];
   if (!lv.set) { set_error("level not set"); return -1; }
   const int dim = lv.dim, NV = ipow(3, dim), NP = ipow(2, dim);
-  // doubles the kernels of this operator write to the slot buffers (the largest path they may take)
+  // doubles the kernels of this operator write to the slot buffers, by the predicates op_velocity and launch_op
+  // choose the path with: brick partial sums, block-boundary slots, or one slot per (cell, local dof)
+  const CoeffData &cd = level == AGMG_ACTIVE ? c->active_coeff() : lv.coeff;
   size_t su = 0, sp = 0;
-  if (which != AGMG_OP_MASS) su = std::max((size_t)NV * lv.cstride * dim, c->scratch_u_need(lv));
-  if (which == AGMG_OP_STOKES || which == AGMG_OP_MASS) sp = (size_t)NP * lv.cstride * dim;
+  if (which != AGMG_OP_MASS) {
+    if (c->bricks_on(lv) && brickq_supported(lv, cd, which)) su = lv.bk.n_partial_slots * 3;
+    else if (c->use_blocks && lv.bt.built && !((cd.newton || cd.dilation) && which == AGMG_OP_STOKES)) su = lv.bt.n_shared_slots * (size_t)dim;
+    else su = (size_t)NV * lv.cstride * dim;
+  }
+  if (which == AGMG_OP_STOKES || which == AGMG_OP_MASS) sp = (size_t)NP * lv.cstride;   // one value per (cell, pressure node)
   su = (su + 31) / 32 * 32;   // keep the second buffer 256-byte aligned
   const size_t need = (su + sp) * sizeof(double);
   if (need > STATIC_SCRATCH_BYTES) {

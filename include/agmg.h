@@ -281,8 +281,11 @@ int agmg_rhs_correction(agmg_ctx *ctx, const double *u0, double *rhs);
  * partial-sum buffers of the kernels live in a static 64 MiB device array of the
  * library (one copy per GPU, held until the process ends) instead of the
  * context's workspace, and no hipMalloc, hipFree or allocating routine is called.
- * Levels whose kernels need more scratch than that are rejected (status -3, the
- * message names both sizes); one-rank contexts only (-2 otherwise).  All calls on
+ * The need follows the kernels the level runs: brick partial sums or
+ * block-boundary slots (a 3-D box of 64^3 cells: 19 MB) or, on the slot path, one
+ * slot per cell dof (170 MB there).  Levels that need more than the array holds are
+ * rejected (status -3, the message names both sizes); one-rank contexts only (-2
+ * otherwise).  All calls on
  * one GPU share the array: calls that overlap on one GPU race. */
 int agmg_vmult_device_noalloc(agmg_ctx *ctx, int which, int level, double *dst, const double *src);
 
@@ -331,7 +334,9 @@ int agmg_bench_vmult(agmg_ctx *ctx, int which, int level, int n_repeat, double *
  * wall time of n_repeat calls of each section.  seconds[0] stokes_vmult, [1] stokes_preconditioner
  * (cheap: 2 V-cycles + B^T), [2] A_preconditioner (one V-cycle), [3] S_preconditioner (one V-cycle),
  * [4] A_block_vmult, [5] set-up of the smoothers (eigenvalue estimates on every level: what the
- * reference redoes inside every solve(), :918-1058). */
+ * reference redoes inside every solve(), :918-1058).  Sections 0-3 are the reference's; 4 and 5 are
+ * this library's own (the reference times Stokes_solve_cheap_idr and Stokes_solve_cheap_gmres there,
+ * :1341-1374: time agmg_solve for those). */
 int agmg_execute_solver_timings(agmg_ctx *ctx, int n_repeat, double seconds[6]);
 
 /* Which kernels apply the velocity-row operators of a level (diagnostics and benchmark reports; the

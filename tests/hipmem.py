@@ -25,6 +25,14 @@ def _ok(rc, what):
         raise RuntimeError(f"{what} failed with hipError {rc}")
 
 
+def free_bytes():
+    """Free device memory of the current device (hipMemGetInfo), after draining the device."""
+    free, total = C.c_size_t(), C.c_size_t()
+    _ok(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")
+    _ok(hip().hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
+    return free.value
+
+
 class DeviceArray:
     """n doubles on the current device."""
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from aspect_amd import capi, cases
-from hipmem import DeviceArray
+from hipmem import DeviceArray, free_bytes
 
 pytestmark = pytest.mark.gpu
 
@@ -46,8 +46,34 @@ def test_noalloc_matches_vmult_device(hip_lib):
         ss.close()
 
 
-def test_noalloc_rejects_levels_beyond_the_scratch(hip_lib):
-    p = cases.convection_box(3, 5).build_single_level()      # 32768 cells: 27 * 3 * 8 B * cells = 21 MB of cell slots fits, r6 would not
+def test_noalloc_allocates_nothing_and_serves_large_levels(hip_lib):
+    """The scratch need follows the path the level takes (brick partial sums / block-boundary slots, not one slot
+    per cell dof): r6 (262144 cells; 170 MB on the slot path) is served from the 64 MiB scratch.  Free device
+    memory (hipMemGetInfo) is the same before and after the calls: nothing was allocated or freed."""
+    p = cases.convection_box(3, 6).build_single_level()
+    s = capi.Solver(hip_lib, p, single_level=True)
+    try:
+        rng = np.random.Generator(np.random.PCG64(6))
+        n = s.size(capi.OP_A)
+        src_h = rng.uniform(-1, 1, n)
+        ref = _device_vmult(hip_lib.vmult_device, s, capi.OP_A, capi.ACTIVE, src_h)   # (allocates the workspace)
+        src, dst = DeviceArray(n).upload(src_h), DeviceArray(n).fill_bytes(0xFF)
+        before = free_bytes()
+        for _ in range(2):
+            s._check(hip_lib.vmult_device_noalloc(s.ctx, capi.OP_A, capi.ACTIVE, dst.ptr, src.ptr))
+        assert free_bytes() == before
+        assert np.array_equal(dst.download(), ref)
+        src.free(); dst.free()
+    finally:
+        s.close()
+
+
+def test_noalloc_rejects_levels_beyond_the_scratch(hip_lib, monkeypatch):
+    # on the slot path (block and brick tables off) r5 = 32768 cells needs 27 * 3 * 8 B * cells = 21 MB: fits;
+    # r6 needs 170 MB > 64 MiB
+    monkeypatch.setenv("AGMG_NO_BLOCKS", "1")
+    monkeypatch.setenv("AGMG_BRICKS", "0")
+    p = cases.convection_box(3, 5).build_single_level()
     s = capi.Solver(hip_lib, p, single_level=True)
     try:
         n = s.size(capi.OP_A)
@@ -56,7 +82,7 @@ def test_noalloc_rejects_levels_beyond_the_scratch(hip_lib):
         assert rc == 0, hip_lib.last_error()
     finally:
         s.close()
-    p = cases.convection_box(3, 6).build_single_level()      # 262144 cells: 170 MB of cell slots > 64 MiB
+    p = cases.convection_box(3, 6).build_single_level()
     s = capi.Solver(hip_lib, p, single_level=True)
     try:
         n = s.size(capi.OP_A)
