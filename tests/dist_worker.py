@@ -142,6 +142,21 @@ def main():
             a = hip.vcycle(which, fin.to_local_v(src) if vel else fin.to_local_p(src))
             check(f"vcycle {which}", relerr(a[lo_], ora.vcycle(which, src)[go_]), 1e-9)
         check("precondition", relerr(hip.precondition(loc.to_local(x))[lo], ora.precondition(x)[go]), 1e-9)
+    if what == "ops" and case == "shell":
+        # configs[3] also solves: 40 cheap iterations (the count to the deck's tolerance is not pinned on this
+        # geometry, tests/test_oracle_goldens.py::test_shell_operators_dense_and_solve), residual history and
+        # iterate against the serial oracle's
+        fin = loc.hier.finest
+        xg, rg, _ = hip.solve(allow_failure=True)
+        xo, ro, _ = ora.solve(allow_failure=True)
+        n = min(rg.n_history, ro.n_history)
+        if not (rg.n_cheap_iterations == ro.n_cheap_iterations == 40 and n >= 40):
+            fails.append(f"shell bounded solve: iterations {rg.n_cheap_iterations} vs {ro.n_cheap_iterations}, history {n}")
+        hg, ho = np.array(rg.history[:n]), np.array(ro.history[:n])
+        check("shell residual history", float(np.max(np.abs(hg - ho) / ho)), 1e-5)
+        check("shell residual reduction", float(hg[n - 1] / hg[0]), 0.2)
+        lo_, go_ = fin.owned_dofs_v()
+        check("shell iterate", relerr(xg[:fin.n_owned_nodes_v * fin.dim], xo[go_]), 1e-5)
     if what == "ops" and ranks.rank == 0:
         print(f"[dist] {case} world={ranks.world} backend={backend}: operators, transfers, V-cycles, preconditioner "
               f"(exchanges {tr.n_exchange}, all-reduces {tr.n_allreduce})", flush=True)

@@ -685,8 +685,9 @@ def test_solcx_goldens_iterations_errors_residual(case, refinement, kw, hip_lib)
 
 
 def test_stokes_golden_iterations_and_velocities(hip_lib):
-    """tests/stokes: 8+0 iterations on the first mesh; 'RMS, max velocity' as far as a uniform mesh can
-    pin it (see tests/test_oracle_goldens.py::test_stokes_rms_and_max_velocity)."""
+    """tests/stokes: 8+0 iterations on the first mesh; the maximum velocity to 8 %; the RMS velocity equal to the
+    oracle's on the same uniform mesh (parity with the reference's adaptive mesh unpinned, see
+    tests/test_oracle_goldens.py::test_stokes_rms_and_max_velocity)."""
     p = cases.stokes_sinker_box(2).build()
     s = capi.Solver(hip_lib, p)
     x, rep, rc = s.solve()
@@ -698,7 +699,8 @@ def test_stokes_golden_iterations_and_velocities(hip_lib):
     s.close()
     rms, vmax = sc.rms_max_velocity(p, x)
     g_rms, g_max = GOLD["stokes"]["rms_max_velocity"][0]
-    assert rc == 0 and abs(vmax / g_max - 1.0) < 0.15 and 1.0 / 6.0 < rms / g_rms < 6.0, (rms, vmax)
+    # (the RMS velocity of the reference's adaptive third mesh is parity unpinned; the oracle's value on this mesh is asserted)
+    assert rc == 0 and abs(vmax / g_max - 1.0) < 0.08 and abs(rms / 6.8161e-11 - 1.0) < 0.01, (rms, vmax)
 
 
 @pytest.mark.parametrize("mesh", [0, 1])
@@ -863,7 +865,9 @@ def test_config4_nsinker_spherical_shell(hip_lib, oracle_lib):
     mesh, tolerance 1e-6, GMRES(200): operators to 1e-12 on every level, the inverse diagonals, the
     right-hand side correction, and the solve (same number of iterations to 2 x tolerance as the
     oracle, see tests/test_oracle_goldens.py::test_shell_operators_dense_and_solve for why not to the
-    tolerance itself; then convergence to the tolerance)."""
+    tolerance itself; then convergence to the tolerance).  Iteration parity with the reference's 106+0 is
+    UNPINNED on this config (same docstring: the floor of the pressure-constant mode sits at 1.07 x tolerance
+    on the stand-in geometry)."""
     p = cases.nsinker_shell(1)
     g, o = make_pair(p, hip_lib, oracle_lib)
     try:

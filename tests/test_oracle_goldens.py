@@ -377,26 +377,31 @@ def test_solcx_error_norms_and_second_iteration_residual(case, refinement, kw):
 
 
 def test_stokes_rms_and_max_velocity():
-    """tests/stokes/screen-output:43 'RMS, max velocity: 3.01e-10 m/s, 1.14e-09 m/s'.  The reference
-    prints it once, for its THIRD mesh (155 cells on 5 levels after two adaptive steps); adaptive meshes
-    are not built here.  A uniform r = 4 mesh has the finest cells of that mesh
-    everywhere: the maximum velocity (inside the sinking sphere) then agrees to 8 %, which pins the
-    scaling of right-hand side, viscosity and pressure block; the RMS velocity (dominated by the far
-    field, which the reference resolves with 722 km cells) only in magnitude.  Exact agreement: parity
-    unpinned until hanging nodes exist."""
-    p = cases.stokes_sinker_box(2).build()
-    s = pyoracle.solver(p)
-    x, rep, rc = s.solve()
-    s.close()
-    assert abs(rep.n_cheap_iterations - G["stokes"]["solves"][0]["cheap"]) <= 1
-    p = cases.stokes_sinker_box(4).build()
-    s = pyoracle.solver(p)
-    x, rep, rc = s.solve()
-    s.close()
-    rms, vmax = sc.rms_max_velocity(p, x)
+    """tests/stokes/screen-output:43 'RMS, max velocity: 3.01e-10 m/s, 1.14e-09 m/s' (statistics: 3.00582157e-10,
+    1.14112361e-09).  The reference prints it once, for its THIRD mesh (155 cells on 5 levels after two adaptive
+    steps); adaptive meshes are not built here.  A uniform r = 4 mesh has the finest cells of
+    that mesh everywhere: the maximum velocity (inside the sinking sphere, which that mesh resolves the same
+    way) agrees to 6 % and pins the scaling of right-hand side, viscosity and pressure block.
+    The RMS velocity is PARITY UNPINNED: on uniform meshes it is 4.02e-11 / 5.47e-11 / 6.82e-11 at r = 2 / 3 / 4
+    (a quarter of the reference's number, still growing by a quarter per refinement as the nodal interpolant
+    of the sphere's indicator sharpens); what the 155-cell mesh with its 722 km far-field cells and hanging
+    nodes makes of it cannot be reproduced before hanging nodes exist.  Asserted instead of a loose bracket
+    around the reference's number: the first mesh's iteration count, the maximum, and this solver's own
+    refinement sequence (regression values above to 1 %)."""
+    want_rms = {2: 4.0238e-11, 3: 5.4745e-11, 4: 6.8161e-11}
     g_rms, g_max = G["stokes"]["rms_max_velocity"][0]
-    assert abs(vmax / g_max - 1.0) < 0.15, (vmax, g_max)
-    assert 1.0 / 6.0 < rms / g_rms < 6.0, (rms, g_rms)
+    for r in (2, 3, 4):
+        p = cases.stokes_sinker_box(r).build()
+        s = pyoracle.solver(p)
+        x, rep, rc = s.solve()
+        s.close()
+        assert rc == 0
+        if r == 2:
+            assert abs(rep.n_cheap_iterations - G["stokes"]["solves"][0]["cheap"]) <= 1
+        rms, vmax = sc.rms_max_velocity(p, x)
+        assert abs(rms / want_rms[r] - 1.0) < 0.01, (r, rms)
+        if r == 4:
+            assert abs(vmax / g_max - 1.0) < 0.08, (vmax, g_max)
 
 
 @pytest.mark.parametrize("mesh", [0, 1])
@@ -629,11 +634,20 @@ def test_shell_operators_dense_and_solve():
     """General-Jacobian operators on the shell: sum-factorised = dense bilinear form on the 96-cell
     mesh; and the config's solve on 768 cells.  The reference (global coarsening, which on a uniformly
     refined mesh has the levels of local smoothing: the box golden tests/nsinker_gmg_gc, 21+0, is
-    reproduced exactly by this oracle) needs 106+0 iterations to 1e-6.  Here the residual falls to
-    2e-6 of the initial one in about as many iterations and then creeps: with Gauss-3 quadrature on a
-    degree-4 mapping B^T 1 is not exactly zero, the pressure constant is a nearly singular mode, and
-    where that plateau sits relative to the tolerance depends on the geometry to more digits than can
-    be reproduced without deal.II.  So the count to 2 x tolerance is what is compared."""
+    reproduced exactly by this oracle) needs 106+0 iterations to 1e-6.
+
+    PARITY UNPINNED on this config, with the cause measured here.  With Gauss-3 quadrature on a degree-4
+    mapping 1^T B is not zero (|B^T 1| = 1.8e-3, 3e-6 of |B^T| on a random vector; the reference has the same
+    quadrature and mapping degree), so the constant pressure is a nearly singular mode and the part of the
+    residual along it stops falling: the history reaches 2 x tolerance at iteration 102 and flattens at
+    1.07 x tolerance, where 96 % of the residual is the constant component of the pressure rows (asserted
+    below).  Whether that floor lands just under the tolerance (106 iterations) or just over it (no
+    convergence within 140) is decided by 7 % of its height, i.e. by the positions of the mesh vertices and
+    mapping support points inside the coarse cells to more digits than the stand-in geometry shares with
+    deal.II's SphericalManifold (the deck's own `Viscosity range` is matched to 2.3e-4).  The reference's
+    caller does nothing about the mode before the solve either (incompressible deck: no
+    make_pressure_rhs_compatible, assembly.cc:887-891; remove_nullspace / normalize_pressure only act on the
+    solution afterwards, stokes_matrix_free_local_smoothing.cc:1539-1541)."""
     p0 = cases.nsinker_shell(0).build()
     s = pyoracle.solver(p0)
     rng = np.random.Generator(np.random.PCG64(3))
@@ -647,11 +661,24 @@ def test_shell_operators_dense_and_solve():
     g = _gold_shell()["spherical_nsinker_gmg_gc"]["solves"][0]
     p = cases.nsinker_shell(1, n_cheap=140).build()
     s = pyoracle.solver(p)
+    nu, n_p = p.hier.finest.n_dofs_v, p.hier.finest.n_dofs_p
+    one = np.zeros(nu + n_p)
+    one[nu:] = 1.0
+    rnd = np.zeros(nu + n_p)
+    rnd[nu:] = rng.uniform(-1, 1, n_p)
+    bt1 = np.linalg.norm(s.vmult(capi.OP_BT, one)[:nu]) / np.sqrt(n_p)
+    btr = np.linalg.norm(s.vmult(capi.OP_BT, rnd)[:nu]) / np.linalg.norm(rnd)
+    assert 1e-7 < bt1 / btr < 1e-5, bt1 / btr              # the constant pressure: nearly, not exactly, in the null space
     x, rep, rc = s.solve(allow_failure=True)
+    r = np.concatenate([p.rhs_u, p.rhs_p]) - s.vmult(capi.OP_STOKES, x)
     s.close()
     hist = np.array(rep.history[:rep.n_history])
     reached = int(np.argmax(hist <= 2.0 * rep.solver_tolerance))
-    assert hist[reached] <= 2.0 * rep.solver_tolerance and abs(reached - g["cheap"]) <= 12, (reached, g["cheap"])
+    assert hist[reached] <= 2.0 * rep.solver_tolerance and abs(reached - g["cheap"]) <= 6, (reached, g["cheap"])
+    # the floor: within 15 % of the tolerance, and made of the constant component of the pressure rows
+    assert 0.85 * rep.solver_tolerance < hist[-1] < 1.15 * rep.solver_tolerance, (hist[-1], rep.solver_tolerance)
+    const_part = abs(r[nu:].sum()) / np.sqrt(n_p)
+    assert const_part > 0.9 * np.linalg.norm(r), (const_part, np.linalg.norm(r))
 
 
 def test_box_global_coarsening_golden_equals_local_smoothing():
