@@ -44,12 +44,12 @@ A_FLOP_PER_CELL = 6800.0     # ~6.8 kflop/cell, Cartesian
 
 
 def measured_traffic(refinement, n_cells):
-    """HBM bytes per A-block vmult from the committed PMC passes (profiles/r2_traffic.json, else
-    r1_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_traffic.sh, gfx950
+    """HBM bytes per A-block vmult from the committed PMC passes (profiles/r3_traffic.json, else the earlier
+    rounds': separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_traffic.sh, gfx950
     correction 2 x FETCH_SIZE, calibrated in profiles/r1_fetch_size_calibration.txt).  bench.py cannot
     run rocprofv3 on itself, so the number is the last committed measurement of this same workload and
     these same kernels, or None."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 e = json.load(f)["convection_box_3d"].get(str(refinement))
@@ -202,7 +202,12 @@ def main():
     t_A = solver.bench_vmult(capi.OP_A, capi.ACTIVE, 100)
     t_S = solver.bench_vmult(capi.OP_STOKES, capi.ACTIVE, 100)
     bytes_A = fin.n_cells * algorithmic_bytes_per_cell(nqv)
-    roof = {"kernel": "A-block vmult = k_cells_blk<A> + k_fix (ABlockOperator::vmult)", "bound": "hbm",
+    def a_block_kernels(s_):
+        nb, z, nblk = s_.kernel_path(capi.ACTIVE)
+        return (f"k_brickq<A> + k_brick_fix ({nb} bricks of 8 x 8 x {z} cells)" if nb else
+                f"k_cells_blk<A> + k_fix ({nblk} blocks)" if nblk else "k_cells<A> + k_pull (slot path)")
+
+    roof = {"kernel": "A-block vmult = " + a_block_kernels(solver) + " (ABlockOperator::vmult)", "bound": "hbm",
             "achieved": bytes_A / t_A / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_A / t_A / 1e9 / HBM_PEAK_GBS,
             "traffic": measured_traffic(args.refinement, fin.n_cells) if world == 1 else None,
@@ -239,6 +244,7 @@ def main():
         tl = sl.bench_vmult(capi.OP_A, capi.ACTIVE, 20)
         bl = fl.n_cells * algorithmic_bytes_per_cell(pl.eta_active.shape[1])
         roof_large = {"workload": f"convection_box_3d r{args.large_refinement} ({fl.n_cells} cells, {fl.n_dofs_v} velocity DoFs)",
+                      "kernel": "A-block vmult = " + a_block_kernels(sl),
                       "achieved": bl / tl / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bl / tl / 1e9 / HBM_PEAK_GBS, "us_per_launch": 1e6 * tl,
                       "traffic": measured_traffic(args.large_refinement, fl.n_cells), "algorithmic_bytes": bl,

@@ -20,7 +20,9 @@ for path in sys.argv[1:]:
         if not m:
             continue
         name = m.group(1)
-        short = "k_brick_fix" if "k_brick_fix" in name else "k_brick" if "k_brick" in name else \
+        if "k_brick_geo" in name:      # coefficient set-up, not part of a vmult
+            continue
+        short = "k_brick_fix" if "k_brick_fix" in name else "k_brickq" if "k_brick" in name else \
                 "k_cells_blk" if "k_cells_blk" in name else "k_fix" if "k_fix" in name else "k_cells"
         d = ast.literal_eval(m.group(2))
         e = kernels.setdefault(short, {"FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0})

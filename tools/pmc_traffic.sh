@@ -16,6 +16,6 @@ for f in glob.glob(out + "/p*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
-    if "k_cells" in k or "k_fix" in k or "k_brick" in k:
+    if ("k_cells" in k or "k_fix" in k or "k_brick" in k) and "k_brick_geo" not in k:   # (k_brick_geo: set-up, not part of a vmult)
         print(k, {c: sum(v) / len(v) for c, v in sorted(d.items())})
 PY
