@@ -82,35 +82,9 @@ class _Space:
                 np.asarray(recv_off, dtype=np.int32))
 
 
-class LocalLevel:
-    """One rank's share of a ``boxmesh.Level``; duck-types it for ``capi.Solver``."""
-
-    def __init__(self, glev, rank, size):
-        self.dim, self.level = glev.dim, glev.level
-        self.rank, self.size = rank, size
-        crank = cell_ranks(glev, size)
-        self.cells = np.flatnonzero(crank == rank)            # global cell ids, contiguous
-        assert self.cells.size and np.all(np.diff(self.cells) == 1)
-        self.n_cells = int(self.cells.size)
-        self.v = _Space(glev.cell_nodes_v.astype(np.int64), crank, glev.n_nodes_v, rank, size)
-        self.p = _Space(glev.cell_nodes_p.astype(np.int64), crank, glev.n_nodes_p, rank, size)
-        self.n_nodes_v, self.n_owned_nodes_v = int(self.v.l2g.size), int(self.v.n_owned)
-        self.n_nodes_p, self.n_owned_nodes_p = int(self.p.l2g.size), int(self.p.n_owned)
-        self.cell_nodes_v = self.v.g2l[glev.cell_nodes_v[self.cells].astype(np.int64)].astype(np.uint32)
-        self.cell_nodes_p = self.p.g2l[glev.cell_nodes_p[self.cells].astype(np.int64)].astype(np.uint32)
-        self.cmask_v = glev.cmask_v[self.v.l2g]
-        self.cmask_p = glev.cmask_p[self.p.l2g]
-        self.cell_h = glev.cell_h[self.cells]
-        self.general = getattr(glev, "general", False)
-        if self.general:
-            self.inv_jacobian = glev.inv_jacobian[self.cells]
-            self.jxw = glev.jxw[self.cells]
-        self.neighbors = sorted(self.v.neighbors | self.p.neighbors)
-        self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
-        self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
-        self.global_nodes_v = self.v.l2g.astype(np.uint32)
-        self.global_nodes_p = self.p.l2g.astype(np.uint32)
-        self.n_global_nodes_v, self.n_global_nodes_p = glev.n_nodes_v, glev.n_nodes_p
+class _LocalVectors:
+    """local <-> global vector helpers shared by the two ways a rank's level comes about (needs self.v.l2g,
+    self.p.l2g, the owned counts and the constraint masks)."""
 
     @property
     def n_dofs_v(self):
@@ -141,6 +115,36 @@ class LocalLevel:
     def owned_dofs_p(self):
         n = self.n_owned_nodes_p
         return np.arange(n), self.p.l2g[:n]
+
+class LocalLevel(_LocalVectors):
+    """One rank's share of a ``boxmesh.Level``; duck-types it for ``capi.Solver``."""
+
+    def __init__(self, glev, rank, size):
+        self.dim, self.level = glev.dim, glev.level
+        self.rank, self.size = rank, size
+        crank = cell_ranks(glev, size)
+        self.cells = np.flatnonzero(crank == rank)            # global cell ids, contiguous
+        assert self.cells.size and np.all(np.diff(self.cells) == 1)
+        self.n_cells = int(self.cells.size)
+        self.v = _Space(glev.cell_nodes_v.astype(np.int64), crank, glev.n_nodes_v, rank, size)
+        self.p = _Space(glev.cell_nodes_p.astype(np.int64), crank, glev.n_nodes_p, rank, size)
+        self.n_nodes_v, self.n_owned_nodes_v = int(self.v.l2g.size), int(self.v.n_owned)
+        self.n_nodes_p, self.n_owned_nodes_p = int(self.p.l2g.size), int(self.p.n_owned)
+        self.cell_nodes_v = self.v.g2l[glev.cell_nodes_v[self.cells].astype(np.int64)].astype(np.uint32)
+        self.cell_nodes_p = self.p.g2l[glev.cell_nodes_p[self.cells].astype(np.int64)].astype(np.uint32)
+        self.cmask_v = glev.cmask_v[self.v.l2g]
+        self.cmask_p = glev.cmask_p[self.p.l2g]
+        self.cell_h = glev.cell_h[self.cells]
+        self.general = getattr(glev, "general", False)
+        if self.general:
+            self.inv_jacobian = glev.inv_jacobian[self.cells]
+            self.jxw = glev.jxw[self.cells]
+        self.neighbors = sorted(self.v.neighbors | self.p.neighbors)
+        self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
+        self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
+        self.global_nodes_v = self.v.l2g.astype(np.uint32)
+        self.global_nodes_p = self.p.l2g.astype(np.uint32)
+        self.n_global_nodes_v, self.n_global_nodes_p = glev.n_nodes_v, glev.n_nodes_p
 
 
 class LocalHierarchy:
@@ -200,3 +204,289 @@ class LocalProblem:
         lu, gu = fin.owned_dofs_v()
         lp, gp = fin.owned_dofs_p()
         return np.concatenate([lu, fin.n_dofs_v + lp]), np.concatenate([gu, gf.n_dofs_v + gp])
+
+
+# ---------------------------------------------------------------------------
+# Rank-local set-up of a structured box: the same tables as LocalLevel / LocalProblem, generated from the rank's own
+# subdomain in closed form -- no rank ever holds the global mesh (what each MPI rank of the reference does:
+# p4est hands it its octants, deal.II numbers its own DoFs, core.cc:141-154, ...local_smoothing.cc:1548-1700).
+# Host memory and set-up time per rank depend on the cells of the rank, not on the number of ranks.
+# ---------------------------------------------------------------------------
+class _ClosedFormSpace:
+    """_Space of a node lattice (Q2: 2 lattice steps per cell, Q1: 1) for the cells of `rank`, from lattice
+    coordinates alone: who touches a node follows from the coarse cells whose closed extent contains it."""
+
+    def __init__(self, cell_lattice_ijk, n1, step, nd, reps, l, rank, size):
+        dim = cell_lattice_ijk.shape[1]
+        strides = np.ones(dim, dtype=np.int64)
+        for d in range(1, dim):
+            strides[d] = strides[d - 1] * nd[d - 1]
+        loc = np.indices((n1,) * dim).reshape(dim, -1)[::-1]         # x fastest
+        gid = np.zeros((cell_lattice_ijk.shape[0], n1 ** dim), dtype=np.int64)
+        for d in range(dim):
+            gid += (step * cell_lattice_ijk[:, d:d + 1] + loc[d][None, :]) * strides[d]
+        uniq, inv = np.unique(gid.reshape(-1), return_inverse=True)   # the nodes this rank touches, ascending
+        # lattice coordinates of the touched nodes
+        X = []
+        rem = uniq
+        for d in range(dim):
+            X.append(rem % nd[d])
+            rem = rem // nd[d]
+        # coarse cells containing a node: one per direction, two on an inner coarse face
+        S = step << l                                                  # lattice steps per coarse cell
+        n_coarse = int(np.prod(reps))
+        per_rank = n_coarse // size
+        lo, hi = [], []
+        for d in range(dim):
+            c_hi = np.minimum(X[d] // S, reps[d] - 1)
+            on_face = (X[d] % S == 0) & (X[d] > 0) & (X[d] < nd[d] - 1)
+            lo.append(np.where(on_face, c_hi - 1, c_hi))
+            hi.append(c_hi)
+        touch = np.zeros(uniq.size, dtype=np.uint64)
+        owner = np.full(uniq.size, size, dtype=np.int64)
+        for combo in range(1 << dim):
+            cid = np.zeros(uniq.size, dtype=np.int64)
+            mul = 1
+            for d in range(dim):
+                cid += (hi[d] if (combo >> d) & 1 else lo[d]) * mul
+                mul *= int(reps[d])
+            r = cid // per_rank
+            touch |= np.uint64(1) << r.astype(np.uint64)
+            owner = np.minimum(owner, r)
+        assert np.all((touch >> np.uint64(rank)) & np.uint64(1) == 1)
+        own_sel = owner == rank
+        owned = np.flatnonzero(own_sel)
+        ghosts = np.flatnonzero(~own_sel)
+        ghosts = ghosts[np.lexsort((uniq[ghosts], owner[ghosts]))]
+        order = np.concatenate([owned, ghosts])                         # local index -> position in uniq
+        self.l2g = uniq[order]
+        self.n_owned = int(owned.size)
+        self.ghost_owner = owner[ghosts]
+        pos2loc = np.empty(uniq.size, dtype=np.int64)
+        pos2loc[order] = np.arange(uniq.size)
+        self.cell_nodes = pos2loc[inv].reshape(gid.shape).astype(np.uint32)
+        self.lattice = np.stack([x[order] for x in X], axis=1)        # lattice coordinates of the local nodes
+        self.export = {}
+        otouch = touch[owned]
+        for k in range(size):
+            if k == rank:
+                continue
+            sel = ((otouch >> np.uint64(k)) & np.uint64(1)) == 1
+            if sel.any():
+                self.export[k] = np.flatnonzero(sel)
+        self.neighbors = set(self.export) | set(int(o) for o in np.unique(self.ghost_owner))
+
+    plan = _Space.plan
+
+
+class RankLocalBoxLevel(_LocalVectors):
+    """Level `l` of a box of `reps` coarse cells as rank `rank` of `size` sees it (a contiguous run of coarse cells
+    and their descendants, cells in Morton order inside a coarse cell): the tables of LocalLevel(boxmesh.Level(...))
+    entry for entry, and enough of boxmesh.Level's interface (cell_ijk, h, qpoint_coords, node coordinates) for the
+    coefficient and right-hand side builders to run on the rank's cells.  Cartesian, non-periodic, lexicographic
+    global numbering."""
+
+    def __init__(self, dim, extents, reps, l, bc, rank, size):
+        from . import boxmesh as bm
+        self.dim, self.level, self.rank, self.size = dim, l, rank, size
+        self.extents = np.asarray(extents, dtype=np.float64)
+        self.reps = np.asarray(reps, dtype=np.int64)
+        self.ncd = self.reps * (1 << l)
+        self.h = self.extents / self.ncd
+        n_coarse = int(np.prod(self.reps))
+        if n_coarse % size:
+            raise ValueError(f"{n_coarse} coarse cells do not split over {size} ranks")
+        per_coarse = 1 << (dim * l)
+        per_rank = n_coarse // size
+        self.cells = np.arange(rank * per_rank * per_coarse, (rank + 1) * per_rank * per_coarse, dtype=np.int64)
+        self.n_cells = int(self.cells.size)
+        self.n_global_cells = n_coarse * per_coarse
+        coarse = self.cells // per_coarse
+        local = bm._morton_decode(self.cells % per_coarse, dim, l)
+        cc, rem = [], coarse
+        for d in range(dim):
+            cc.append(rem % self.reps[d])
+            rem = rem // self.reps[d]
+        self.cell_ijk = np.stack([cc[d] * (1 << l) + local[d] for d in range(dim)], axis=1)
+        self.nvd, self.npd = 2 * self.ncd + 1, self.ncd + 1
+        self.n_global_nodes_v, self.n_global_nodes_p = int(np.prod(self.nvd)), int(np.prod(self.npd))
+        self.v = _ClosedFormSpace(self.cell_ijk, 3, 2, self.nvd, self.reps, l, rank, size)
+        self.p = _ClosedFormSpace(self.cell_ijk, 2, 1, self.npd, self.reps, l, rank, size)
+        self.cell_nodes_v, self.cell_nodes_p = self.v.cell_nodes, self.p.cell_nodes
+        self.n_nodes_v, self.n_owned_nodes_v = int(self.v.l2g.size), self.v.n_owned
+        self.n_nodes_p, self.n_owned_nodes_p = int(self.p.l2g.size), self.p.n_owned
+        # constraint masks (boxmesh.Level._constraint_mask on the rank's nodes)
+        mask = np.zeros(self.n_nodes_v, dtype=np.uint8)
+        allbits = (1 << dim) - 1
+        for d in range(dim):
+            for side in range(2):
+                code = bc[2 * d + side]
+                on = self.v.lattice[:, d] == (0 if side == 0 else self.nvd[d] - 1)
+                if code == bm.BC_ZERO:
+                    mask[on] |= allbits
+                elif code == bm.BC_TANGENTIAL:
+                    mask[on] |= (1 << d)
+                elif code >= bm.BC_COMPONENTS:
+                    mask[on] |= (code - bm.BC_COMPONENTS) & allbits
+        self.cmask_v = mask
+        self.cmask_p = np.zeros(self.n_nodes_p, dtype=np.uint8)
+        self.cell_h = np.tile(self.h, (self.n_cells, 1))
+        self.general = False
+        self.periodic = [False] * dim
+        self.neighbors = sorted(self.v.neighbors | self.p.neighbors)
+        self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
+        self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
+        self.global_nodes_v = self.v.l2g.astype(np.uint32)
+        self.global_nodes_p = self.p.l2g.astype(np.uint32)
+
+    # -- the part of boxmesh.Level's interface the table builders use, on the rank's cells and nodes
+    def node_coords_v(self):
+        return self.v.lattice * (self.h / 2)[None, :]
+
+    def node_coords_p(self):
+        return self.p.lattice * self.h[None, :]
+
+    def qpoint_coords(self, cell_ijk=None):
+        from . import boxmesh as bm
+        ijk = self.cell_ijk if cell_ijk is None else cell_ijk
+        q = np.indices((3,) * self.dim).reshape(self.dim, -1)[::-1]
+        out = np.zeros((ijk.shape[0], 3 ** self.dim, self.dim))
+        for d in range(self.dim):
+            out[:, :, d] = (ijk[:, d:d + 1] + bm.GAUSS3_X[q[d]][None, :]) * self.h[d]
+        return out
+
+    def halo_cells(self):
+        """Lattice positions [n, dim] of the cells of OTHER ranks that touch a node of this rank (one layer around the
+        subdomain): their element vectors complete the sums at the rank's shared nodes without any exchange."""
+        dim = self.dim
+        shared = np.zeros(self.n_nodes_v, dtype=bool)
+        shared[self.n_owned_nodes_v:] = True
+        for e in self.v.export.values():
+            shared[e] = True
+        surf = self.cell_ijk[shared[self.cell_nodes_v.astype(np.int64)].any(axis=1)]
+        if surf.shape[0] == 0:
+            return np.zeros((0, dim), dtype=np.int64)
+        offs = np.indices((3,) * dim).reshape(dim, -1).T - 1
+        cand = (surf[:, None, :] + offs[None, :, :]).reshape(-1, dim)
+        ok = np.all((cand >= 0) & (cand < self.ncd[None, :]), axis=1)
+        cand = cand[ok]
+        mul = np.concatenate([[1], np.cumprod(self.ncd[:-1])]).astype(np.int64)
+        ids = np.unique(cand @ mul)
+        ids = ids[~np.isin(ids, self.cell_ijk @ mul)]
+        out = np.zeros((ids.size, dim), dtype=np.int64)
+        rem = ids
+        for d in range(dim):
+            out[:, d] = rem % self.ncd[d]
+            rem = rem // self.ncd[d]
+        return out
+
+    def local_nodes_of(self, cell_ijk):
+        """Local Q2 node indices [n, 3^dim] of arbitrary cells of the level (-1: not a node of this rank)."""
+        dim = self.dim
+        strides = np.ones(dim, dtype=np.int64)
+        for d in range(1, dim):
+            strides[d] = strides[d - 1] * self.nvd[d - 1]
+        loc = np.indices((3,) * dim).reshape(dim, -1)[::-1]
+        gid = np.zeros((cell_ijk.shape[0], 3 ** dim), dtype=np.int64)
+        for d in range(dim):
+            gid += (2 * cell_ijk[:, d:d + 1] + loc[d][None, :]) * strides[d]
+        srt = np.argsort(self.v.l2g, kind="stable")
+        pos = np.searchsorted(self.v.l2g[srt], gid)
+        pos = np.minimum(pos, srt.size - 1)
+        hit = self.v.l2g[srt][pos] == gid
+        return np.where(hit, srt[pos], -1)
+
+
+class RankLocalHierarchy:
+    def __init__(self, dim, refinement, extents, reps, bc, rank, size, only_finest=False):
+        self.dim, self.rank, self.size = dim, rank, size
+        first = refinement if only_finest else 0
+        self.levels = [RankLocalBoxLevel(dim, extents, reps, l, bc, rank, size) for l in range(first, refinement + 1)]
+
+    @property
+    def finest(self):
+        return self.levels[-1]
+
+    @property
+    def n_levels(self):
+        return len(self.levels)
+
+
+class RankLocalProblem:
+    """LocalProblem without a global problem: built from an UNBUILT ``cases.StokesProblem`` of a Cartesian box.
+    Coefficient tables come from the material at the rank's own quadrature points; the right-hand side from the
+    rank's cells plus the one layer of neighbouring cells that share its nodes (same sums as the global assembly up
+    to their order).  eta_min / eta_max are the rank's own (reporting only)."""
+
+    def __init__(self, case, rank, size, only_finest=False):
+        from . import boxmesh as bm
+        if case.deform is not None or case.periodic or case.make_hierarchy is not None or case.numbering != "lexicographic":
+            raise ValueError("rank-local set-up: Cartesian non-periodic boxes with lexicographic numbering only")
+        if case.boundary_traction or case.dilation_rhs is not None or case.free_surface_spec or case.boundary_velocity or \
+           case.eta_q is not None or case.pressure_scaling_from_mesh is not None:
+            raise ValueError("rank-local set-up: this deck needs tables that are only built from the global mesh")
+        self.case, self.rank, self.size = case, rank, size
+        for k in ("name", "dim", "tol", "restart", "n_cheap", "n_expensive", "krylov", "idr_s", "pressure_scaling", "is_compressible"):
+            setattr(self, k, getattr(case, k, None))
+        dim = case.dim
+        extents = [1.0] * dim if case.extents is None else case.extents
+        reps = [1] * dim if case.reps is None else case.reps
+        self.hier = RankLocalHierarchy(dim, case.refinement, extents, reps, case.bc, rank, size, only_finest)
+        fin = self.hier.finest
+        if only_finest:
+            nq = 3 ** dim
+            eta_q = case.eta(fin.qpoint_coords().reshape(-1, dim)).reshape(fin.n_cells, nq)
+            self.eta_active = (nq / np.sum(1.0 / eta_q, axis=1))[:, None] if case.averaging == bm.AVG_HARMONIC else eta_q
+            self.eta_levels = [self.eta_active]
+            self.eta_min, self.eta_max = float(self.eta_active.min()), float(self.eta_active.max())
+        else:
+            self.eta_active, self.eta_levels, self.eta_min, self.eta_max = bm.viscosity_tables(self.hier, case.eta, case.averaging)
+        self.free_surface = None
+        self.dilation = None
+        # right-hand side: own cells, then the halo cells' shares of the rank's nodes
+        Nq = bm.tensor_shape([bm.N2] * dim)
+        W = bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * dim).reshape(-1) * np.prod(fin.h)
+        out = np.zeros((fin.n_nodes_v, dim))
+
+        def add(cell_ijk, nodes):
+            if case.force_q is not None:
+                raise ValueError("rank-local set-up: FE-field densities need the global mesh")
+            xq = fin.qpoint_coords(cell_ijk)
+            f = case.force(xq.reshape(-1, dim)).reshape(cell_ijk.shape[0], -1, dim)
+            loc = np.matmul((Nq * W[:, None]).T[None, :, :], f)          # [cell][i][d] = sum_q N_i(q) W_q f(q)
+            keep = nodes >= 0
+            np.add.at(out, nodes[keep], loc[keep])
+
+        add(fin.cell_ijk, fin.cell_nodes_v.astype(np.int64))
+        halo = fin.halo_cells()
+        if halo.shape[0]:
+            add(halo, fin.local_nodes_of(halo))
+        out = out.reshape(-1)
+        out[fin.constrained_dofs_v()] = 0.0
+        self.rhs_u = out
+        self.rhs_p = np.zeros(fin.n_dofs_p)
+        if case.initial_pressure is not None:
+            self.p0 = case.initial_pressure(fin.node_coords_p()) / self.pressure_scaling
+        else:
+            self.p0 = np.zeros(fin.n_dofs_p)
+        self.n_global_dofs_v = fin.n_global_nodes_v * dim
+        self.n_global_dofs_p = fin.n_global_nodes_p
+
+    def to_local(self, g):
+        """global block vector [u; p] -> local block vector (tests on small meshes)."""
+        fin = self.hier.finest
+        return np.concatenate([fin.to_local_v(g[:self.n_global_dofs_v]), fin.to_local_p(g[self.n_global_dofs_v:])])
+
+    def owned_block(self):
+        fin = self.hier.finest
+        lu, gu = fin.owned_dofs_v()
+        lp, gp = fin.owned_dofs_p()
+        return np.concatenate([lu, fin.n_dofs_v + lp]), np.concatenate([gu, self.n_global_dofs_v + gp])
+
+    def global_index_vector(self):
+        """Global index of every local entry of a block vector [u; p] (synthetic inputs that are a function of the
+        global index, generated without a global vector)."""
+        fin = self.hier.finest
+        d = self.dim
+        gu = (fin.v.l2g[:, None] * d + np.arange(d)[None, :]).reshape(-1)
+        return np.concatenate([gu, self.n_global_dofs_v + fin.p.l2g])

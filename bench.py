@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--refinement", type=int, default=5, help="configs[1]: convection_box_3d, global refinement 5")
     ap.add_argument("--large-refinement", type=int, default=7,
                     help="extra A-block roofline point on a level that fills the chip (0 = skip)")
-    ap.add_argument("--scale-refinement", type=int, default=6,
+    ap.add_argument("--scale-refinement", type=int, default=7,
                     help="N > 1: also time the distributed Stokes vmult and solve with this refinement per GPU, next to "
                          "the same cube on one GPU (0 = skip); `value` stays configs[1] per GPU for every N")
     ap.add_argument("--config3-refinement", type=int, default=6,
@@ -105,6 +105,7 @@ def main():
         return prob, solver, fin, src_h, fin.n_dofs_v, fin.n_dofs_p
 
     transport_name = ""
+    comm_counts = {}
 
     def distributed_setup(refinement=None):
         nonlocal transport_name
@@ -113,14 +114,15 @@ def main():
         reps = {2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}.get(world)
         if reps is None:
             raise ValueError(f"no subdomain layout for {world} ranks")
+        # rank-local set-up: every rank generates its own subdomain (one unit cube of the box of `reps` cubes) in
+        # closed form, never the global mesh -- host memory and set-up time per rank do not depend on N
+        # (tests/test_host_and_abi.py: the tables equal the partition of the global mesh entry for entry)
         g = cases.convection_box(3, refinement or args.refinement)
         g.reps, g.extents = reps, [float(r) for r in reps]
-        g.build()
-        loc = partition.LocalProblem(g, rank, world)
-        gf = g.hier.finest
-        src_g = np.sin(0.37 * np.arange(gf.n_dofs_v + gf.n_dofs_p))
-        src_g[:gf.n_dofs_v][gf.constrained_dofs_v()] = 0.0
-        src_l = loc.to_local(src_g)
+        loc = partition.RankLocalProblem(g, rank, world)
+        lf = loc.hier.finest
+        src_l = np.sin(0.37 * loc.global_index_vector())          # the same global vector as on one rank
+        src_l[:lf.n_dofs_v][lf.constrained_dofs_v()] = 0.0
         own = loc.owned_block()[0]
 
         def one_vmult(solver):
@@ -131,9 +133,18 @@ def main():
             torch.cuda.synchronize()
             return d_.cpu().numpy()[own]
 
-        # reference transport: torch.distributed callbacks (RCCL point-to-point through PyTorch)
-        solver = capi.Solver(lib, loc, transport=Transport(ranks), device=local_rank)
+        # reference transport: torch.distributed callbacks (RCCL point-to-point through PyTorch); it counts the
+        # messages: ghost exchanges and all-reduces per Krylov iteration of a solve (configs[1] only: one more solve)
+        tr0 = Transport(ranks)
+        solver = capi.Solver(lib, loc, transport=tr0, device=local_rank)
         ref = one_vmult(solver)
+        if refinement is None:
+            _, _, _ = solver.solve(allow_failure=True)
+            e0, a0 = tr0.n_exchange, tr0.n_allreduce
+            _, rep_c, _ = solver.solve(allow_failure=True)
+            its = max(1, rep_c.n_cheap_iterations + rep_c.n_expensive_iterations)
+            comm_counts.update({"gmres_iterations": its, "ghost_exchanges_per_iteration": (tr0.n_exchange - e0) / its,
+                                "all_reduces_per_iteration": (tr0.n_allreduce - a0) / its})
         transport_name = "torch.distributed callbacks"
         want = os.environ.get("AGMG_TRANSPORT", "rccl" if backend == "nccl" else "torch")
         if want == "rccl":
@@ -153,7 +164,7 @@ def main():
                 solver = native
                 transport_name = "in-library RCCL (grouped ncclSend/ncclRecv + ncclAllReduce on the library stream)"
         # whole-job DoFs / N = DoFs per GPU (owned)
-        return loc, solver, loc.hier.finest, src_l, gf.n_dofs_v / world, gf.n_dofs_p / world
+        return loc, solver, lf, src_l, loc.n_global_dofs_v / world, loc.n_global_dofs_p / world
 
     parallelism = "1 rank"
     if world > 1:
@@ -366,7 +377,7 @@ def main():
                 "config": {"workload": f"cookbooks/convection_box_3d, global refinement {args.refinement}, "
                                        f"{fin.n_cells} cells, {int(nu)}+{int(npd)} DoFs per GPU, per-q viscosity tables",
                            "parallelism": parallelism},
-                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, "config3_nsinker": config3, "weak_scaling_larger_cube": scale_large,
+                "roofline": roof, "cpu_baseline": cpu, "roofline_large": roof_large, "config3_nsinker": config3, "weak_scaling_larger_cube": scale_large, "messages_per_krylov_iteration": comm_counts or None,
                 **extra}
         print(json.dumps(line))
     ranks.close()

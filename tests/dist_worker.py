@@ -28,8 +28,10 @@ def relerr(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def global_problem(case, world):
+def global_problem(case, world, build=True):
     reps = {1: [1, 1, 1], 2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}[world]
+    if case.endswith("_ranklocal"):   # partition.RankLocalProblem: every rank builds its own subdomain only
+        case = case[:-len("_ranklocal")]
     if case == "nsinker":
         p = cases.nsinker_box(2, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE)
     elif case == "nsinker_idr":   # SolverIDR(2) as the cheap solver (tests/nsinker_gmg_idr.prm)
@@ -56,7 +58,7 @@ def global_problem(case, world):
     p.reps = reps
     if case != "deformed":   # the deformation map is written for the unit box
         p.extents = [float(r) for r in reps]
-    return p.build()
+    return p.build() if build else p
 
 
 def main():
@@ -69,7 +71,12 @@ def main():
     ranks = parallel.Ranks(backend=backend.split("-")[0], device=dev)
     tr = parallel.Transport(ranks, device_buffers=1 if backend == "gloo-dev" else None)
     g = global_problem(case, ranks.world)
-    loc = partition.LocalProblem(g, ranks.rank, ranks.world)
+    if case.endswith("_ranklocal"):
+        # the rank's tables in closed form from its own subdomain (no global mesh on the product side; the global
+        # problem above is the serial oracle's)
+        loc = partition.RankLocalProblem(global_problem(case, ranks.world, build=False), ranks.rank, ranks.world)
+    else:
+        loc = partition.LocalProblem(g, ranks.rank, ranks.world)
     hip = capi.Solver(capi.load(), loc, transport=tr, device=dev.index)
     ora = pyoracle.solver(g)
     fails = []

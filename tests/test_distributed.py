@@ -68,6 +68,8 @@ def test_world_size_2_gloo_partition_and_transport():
                                              (8, "shell", "gloo"), (2, "shell", "gloo-dev"),
                                              # several blocks per rank: the interior ones run under the ghost import
                                              (2, "nsinker_r3", "gloo"), (2, "nsinker_r3", "gloo-dev"), (4, "box3d_r3", "gloo-dev"),
+                                             # rank-local set-up: every rank generates only its own subdomain
+                                             (2, "nsinker_r3_ranklocal", "gloo-dev"), (8, "box3d_ranklocal", "gloo"),
                                              # device-pointer protocol of the communicator (what RCCL uses)
                                              (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
 def test_distributed_hip_matches_serial_oracle(nproc, case, wire):

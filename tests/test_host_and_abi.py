@@ -138,3 +138,35 @@ def test_simd_cpu_baseline_matches_the_oracle(oracle_lib):
                 assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(a), which
         finally:
             o.close()
+
+
+@pytest.mark.parametrize("refinement,reps,size", [(2, [2, 1, 1], 2), (1, [2, 2, 2], 8), (2, [2, 2, 2], 2), (2, [4, 1, 1], 2)])
+def test_rank_local_setup_equals_partition_of_the_global_mesh(refinement, reps, size):
+    """partition.RankLocalProblem (each rank generates its own subdomain in closed form, BASELINE configs[4]'s
+    set-up) against partition.LocalProblem cut out of the global mesh: every table of every level entry for entry
+    (numbering, ownership, exchange plans, constraint masks), the coefficient tables bit for bit, the right-hand
+    side to rounding (own cells plus a halo layer instead of the global assembly: another order of the sums)."""
+    from aspect_amd import partition
+
+    def case():
+        c = cases.nsinker_box(refinement, n_sinkers=4, ratio=1e4)
+        c.reps, c.extents = reps, [float(x) for x in reps]
+        return c
+
+    g = case().build()
+    keys = ("cells", "n_cells", "n_nodes_v", "n_owned_nodes_v", "n_nodes_p", "n_owned_nodes_p", "cell_nodes_v", "cell_nodes_p",
+            "cmask_v", "cmask_p", "cell_h", "neighbors", "send_offsets_v", "send_nodes_v", "recv_offsets_v", "send_offsets_p",
+            "send_nodes_p", "recv_offsets_p", "global_nodes_v", "global_nodes_p", "n_global_nodes_v", "n_global_nodes_p")
+    for rank in range(size):
+        a, b = partition.LocalProblem(g, rank, size), partition.RankLocalProblem(case(), rank, size)
+        assert a.hier.n_levels == b.hier.n_levels
+        for la, lb in zip(a.hier.levels, b.hier.levels):
+            for k in keys:
+                assert np.array_equal(np.asarray(getattr(la, k)), np.asarray(getattr(lb, k))), (rank, la.level, k)
+        for ta, tb in zip(a.eta_levels + [a.eta_active], b.eta_levels + [b.eta_active]):
+            assert np.array_equal(ta, tb)
+        assert np.allclose(a.rhs_u, b.rhs_u, rtol=1e-13, atol=1e-13 * np.abs(a.rhs_u).max())
+        assert np.array_equal(a.p0, b.p0) and np.array_equal(a.rhs_p, b.rhs_p)
+        x = np.arange(g.hier.finest.n_dofs_v + g.hier.finest.n_dofs_p, dtype=np.float64)
+        assert np.array_equal(a.to_local(x), b.to_local(x)) and np.array_equal(b.to_local(x), b.global_index_vector())
+        assert all(np.array_equal(p, q) for p, q in zip(a.owned_block(), b.owned_block()))
