@@ -128,14 +128,47 @@ namespace aspect
             flatten_level(mf, mf_p, level, &h.mg_constrained_dofs_A_block, level > 0 ? &level_cells[level - 1] : nullptr,
                           level_cells[level]);
           }
-        // the active mesh of a uniformly refined triangulation is its finest level with identical numbering only if
-        // the active DoFHandler was numbered like the level one; deal.II gives no such promise, so the active mesh
-        // is flattened in its own right and the transfer between the two is the identity on cells
-        {
-          const MatrixFree<dim, double> &mf = *h.matrix_free_objects[0];      // stokes_dofs {v, p}, :1727-1731
-          std::map<CellId, int> none;
-          flatten_level(mf, mf, numbers::invalid_unsigned_int, nullptr, nullptr, active_cells);
-        }
+        // The library's active mesh IS its finest level (agmg_set_level(AGMG_ACTIVE, NULL): uniformly refined meshes).
+        // deal.II numbers the active DoFs and the level DoFs of the finest level independently, so vectors and
+        // tables of the active mesh are permuted into the level's numbering / cell order here: the same cells carry
+        // both numberings.
+        check(agmg_set_level(ctx, AGMG_ACTIVE, nullptr), "agmg_set_level(active)");
+        build_active_permutation(n_levels - 1);
+      }
+
+      // active local dof -> local dof of the finest level (velocity and pressure), and the position of every active
+      // cell in the level's flattened order
+      void build_active_permutation(const unsigned int finest)
+      {
+        const MatrixFree<dim, double> &mf_a = *h.matrix_free_objects[0];
+        const MatrixFree<dim, double> &mf_l = *h.mg_matrices_A_block[finest].get_matrix_free();
+        const MatrixFree<dim, double> &mf_lp = *h.mg_matrices_Schur_complement[finest].get_matrix_free();
+        const Utilities::MPI::Partitioner &pa_v = *mf_a.get_vector_partitioner(0), &pa_p = *mf_a.get_vector_partitioner(1);
+        const Utilities::MPI::Partitioner &pl_v = *mf_l.get_vector_partitioner(0), &pl_p = *mf_lp.get_vector_partitioner(0);
+        perm_v.assign(pa_v.locally_owned_size() + pa_v.n_ghost_indices(), numbers::invalid_unsigned_int);
+        perm_p.assign(pa_p.locally_owned_size() + pa_p.n_ghost_indices(), numbers::invalid_unsigned_int);
+        std::vector<types::global_dof_index> a(h.fe_v.n_dofs_per_cell()), l(h.fe_v.n_dofs_per_cell());
+        std::vector<types::global_dof_index> ap(h.fe_p.n_dofs_per_cell()), lp(h.fe_p.n_dofs_per_cell());
+        active_position.clear();
+        for (unsigned int batch = 0; batch < mf_a.n_cell_batches(); ++batch)
+          for (unsigned int lane = 0; lane < mf_a.n_active_entries_per_cell_batch(batch); ++lane)
+            {
+              const auto cv = mf_a.get_cell_iterator(batch, lane, 0);
+              const auto cp = mf_a.get_cell_iterator(batch, lane, 1);
+              AssertThrow(static_cast<unsigned int>(cv->level()) == finest, ExcMessage("active cell below the finest level"));
+              cv->get_dof_indices(a);
+              cv->get_mg_dof_indices(l);
+              cp->get_dof_indices(ap);
+              cp->get_mg_dof_indices(lp);
+              for (unsigned int i = 0; i < a.size(); ++i)
+                perm_v[pa_v.global_to_local(a[i])] = pl_v.global_to_local(l[i]);
+              for (unsigned int i = 0; i < ap.size(); ++i)
+                perm_p[pa_p.global_to_local(ap[i])] = pl_p.global_to_local(lp[i]);
+              active_position.push_back(level_cells[finest].at(cv->id()));
+            }
+        n_level_dofs_v = pl_v.locally_owned_size() + pl_v.n_ghost_indices();
+        n_level_dofs_p = pl_p.locally_owned_size() + pl_p.n_ghost_indices();
+        n_level_owned_v = pl_v.locally_owned_size();
       }
 
       // ------------------------------------------------------------------ assemble() = evaluate_material_model() +
@@ -281,42 +314,48 @@ namespace aspect
       agmg_ctx *ctx;
       // position of every cell in the flattened order of its level (parents are looked up by CellId)
       std::vector<std::map<CellId, int>> level_cells;
-      std::map<CellId, int> active_cells;
+      std::vector<unsigned int> perm_v, perm_p;      // active local dof -> local dof of the finest level
+      std::vector<int> active_position;              // active cell (MatrixFree batch order) -> cell of the finest level
+      std::size_t n_level_dofs_v = 0, n_level_dofs_p = 0, n_level_owned_v = 0;
 
       void check(const int status, const char *what) const
       {
         AssertThrow(status == 0, ExcMessage(std::string(what) + ": " + agmg_last_error()));
       }
 
-      // ---- block vector <-> the flat rank-local vector [velocity (dof = dim * node + component) ; pressure]:
-      // owned entries first, ghosts behind them, per block -- exactly the storage of a
-      // LinearAlgebra::distributed::Vector initialised by MatrixFree::initialize_dof_vector
+      // ---- block vector (active numbering, MatrixFree partitioner layout: owned entries first, ghosts behind them)
+      // <-> the flat rank-local vector of the library [velocity (dof = dim * node + component) ; pressure] in the
+      // numbering of the finest level.  A rank owns the same cells on the active mesh and on the finest level, so an
+      // owned active dof maps to an owned level dof.
       void to_flat(const BlockVectorType &v, std::vector<double> &flat) const
       {
         const VectorType &u = v.block(0), &p = v.block(1);
-        const std::size_t nu = u.locally_owned_size() + u.get_partitioner()->n_ghost_indices();
-        const std::size_t np = p.locally_owned_size() + p.get_partitioner()->n_ghost_indices();
-        flat.resize(nu + np);
-        std::copy(u.begin(), u.begin() + nu, flat.begin());               // (ghost entries are refreshed by the library)
-        std::copy(p.begin(), p.begin() + np, flat.begin() + nu);
+        flat.assign(n_level_dofs_v + n_level_dofs_p, 0.0);
+        for (unsigned int i = 0; i < perm_v.size(); ++i)
+          if (perm_v[i] != numbers::invalid_unsigned_int)
+            flat[perm_v[i]] = u.local_element(i);                         // (ghost entries are refreshed by the library)
+        for (unsigned int i = 0; i < perm_p.size(); ++i)
+          if (perm_p[i] != numbers::invalid_unsigned_int)
+            flat[n_level_dofs_v + perm_p[i]] = p.local_element(i);
       }
 
       void from_flat(const std::vector<double> &flat, BlockVectorType &v) const
       {
         VectorType &u = v.block(0), &p = v.block(1);
-        std::copy(flat.begin(), flat.begin() + u.locally_owned_size(), u.begin());
-        const std::size_t nu = u.locally_owned_size() + u.get_partitioner()->n_ghost_indices();
-        std::copy(flat.begin() + nu, flat.begin() + nu + p.locally_owned_size(), p.begin());
+        for (unsigned int i = 0; i < u.locally_owned_size(); ++i)
+          u.local_element(i) = flat[perm_v[i]];
+        for (unsigned int i = 0; i < p.locally_owned_size(); ++i)
+          p.local_element(i) = flat[n_level_dofs_v + perm_p[i]];
       }
 
-      // ---- one level (level == invalid_unsigned_int: the active mesh) -> agmg_level_desc
+      // ---- one multigrid level -> agmg_level_desc
       // mf: MatrixFree whose dof handler 0 is dof_handler_v; mf_p: the one whose last dof handler is dof_handler_p
       // (the level objects of the A block and of the Schur complement; on the active mesh both are matrix_free_objects[0])
       void flatten_level(const MatrixFree<dim, double> &mf, const MatrixFree<dim, double> &mf_p, const unsigned int level,
                          const MGConstrainedDoFs *mg_constrained_v, const std::map<CellId, int> *coarser,
                          std::map<CellId, int> &positions)
       {
-        const bool active = level == numbers::invalid_unsigned_int;
+        const bool active = false;
         const unsigned int comp_v = 0, comp_p = (&mf == &mf_p) ? 1 : 0;
         const Utilities::MPI::Partitioner &part_v = *mf.get_vector_partitioner(comp_v);
         const Utilities::MPI::Partitioner &part_p = *mf_p.get_vector_partitioner(comp_p);
@@ -454,7 +493,7 @@ namespace aspect
         d.recv_offsets_p = recv_off_p.data();
         d.global_nodes_v = global_v.data();
         d.global_nodes_p = global_p.data();
-        check(agmg_set_level(ctx, active ? AGMG_ACTIVE : static_cast<int>(level), &d), "agmg_set_level");
+        check(agmg_set_level(ctx, static_cast<int>(level), &d), "agmg_set_level");
       }
 
       // neighbours = union of the ranks of both spaces, ascending; per neighbour the owned nodes it ghosts and the
@@ -518,6 +557,8 @@ namespace aspect
         constexpr unsigned int nq = Utilities::pow(3, dim), nsym = dim * (dim + 1) / 2;
         std::vector<double> eta, strain, dEde, dEdp, dil_lhs, dil_de, dil_dp;
         const bool newton = cd.enable_newton_derivatives, dilation = cd.enable_prescribed_dilation;
+        // (level tables: the flattened order IS the batch order of the level's MatrixFree.  Active tables: rows are
+        // produced in the batch order of the active MatrixFree and moved to the level's cell order afterwards.)
         for (unsigned int batch = 0; batch < mf.n_cell_batches(); ++batch)
           for (unsigned int lane = 0; lane < mf.n_active_entries_per_cell_batch(batch); ++lane)
             {
@@ -547,6 +588,21 @@ namespace aspect
                       }
                   }
             }
+        if (level == AGMG_ACTIVE)
+          {
+            const auto reorder = [&](std::vector<double> &t, const unsigned int width)
+            {
+              if (t.empty())
+                return;
+              std::vector<double> out(t.size());
+              for (std::size_t cell = 0; cell < active_position.size(); ++cell)
+                std::copy(t.begin() + cell * width, t.begin() + (cell + 1) * width, out.begin() + std::size_t(active_position[cell]) * width);
+              t.swap(out);
+            };
+            reorder(eta, nq_table);
+            reorder(strain, nq * nsym); reorder(dEde, nq * nsym); reorder(dEdp, nq);
+            reorder(dil_lhs, nq); reorder(dil_de, nq * nsym); reorder(dil_dp, nq);
+          }
         agmg_cell_data d = {};
         d.is_compressible = cd.is_compressible ? 1 : 0;
         d.enable_newton_derivatives = newton ? 1 : 0;
@@ -591,7 +647,7 @@ namespace aspect
             for (unsigned int lane = 0; lane < mf.n_active_entries_per_face_batch(face); ++lane)
               {
                 const auto cf = mf.get_face_iterator(face, lane, true);        // (cell, face number)
-                face_cell.push_back(static_cast<uint32_t>(active_cells.at(cf.first->id())));
+                face_cell.push_back(static_cast<uint32_t>(level_cells.back().at(cf.first->id())));
                 face_number.push_back(static_cast<uint8_t>(cf.second));
                 for (unsigned int q = 0; q < nqf; ++q)
                   {
