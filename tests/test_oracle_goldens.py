@@ -263,6 +263,100 @@ def test_periodic_box_tables_transfer_and_solve():
     s.close()
 
 
+def test_periodic_levels_without_periodicity_cost_what_the_reference_pays():
+    """Second candidate for the 53+0 of tests/periodic_box_gmg (11 here), tested: the reference builds the
+    constraints of its LEVEL operators from the boundary indices and the no-normal-flux constraints only
+    (stokes_matrix_free_local_smoothing.cc:1771-1822); periodicity reaches its level vectors through
+    MGConstrainedDoFs in the transfers, so its smoothers see a box with natural conditions on the periodic faces
+    and two copies of every periodic DoF (its DoF counts, 8,450+1,089 for 1024 cells and a coarse level of 18+4,
+    are the unmerged ones).  Restated with what the oracle offers: the block preconditioner (stokes_matrix_free.h:
+    237-354) written out around V-cycles, checked against the oracle's own on the periodic hierarchy, then run with
+    the V-cycles of a NON-periodic hierarchy of the same box (residual copied to the master copy, zero on the slave
+    copy, correction read from the master copy).  11 iterations become 39 (33-47 over the other ways of copying
+    between the two numberings): the reference's count is what a level hierarchy that ignores periodicity costs.
+    Pinning 53 itself would need deal.II's exact handling of the periodic level constraints inside MGTransferMF:
+    the periodic solve stays PARITY UNPINNED, with this as the measured explanation."""
+    pp = cases.periodic_box_2d(5).build()
+    pn = cases.periodic_box_2d(5)
+    pn.periodic = None
+    pn.build()
+    sp_, sn = pyoracle.solver(pp), pyoracle.solver(pn)
+    sp_.setup_smoothers()
+    sn.setup_smoothers()
+    fp, fn = pp.hier.finest, pn.hier.finest
+    nu, n_p, dim = fp.n_dofs_v, fp.n_dofs_p, 2
+
+    def maps(nd_per, nd_non):       # non-periodic node -> periodic node, and which non-periodic nodes are master copies
+        i, j = np.meshgrid(np.arange(nd_non[0]), np.arange(nd_non[1]), indexing="xy")
+        return ((i % nd_per[0]) + nd_per[0] * j).reshape(-1), (i < nd_per[0]).reshape(-1)
+
+    tv, mv = maps(fp.nvd, fn.nvd)
+    tp, mp = maps(fp.npd, fn.npd)
+
+    def vcycle_non(which, r):
+        if which == capi.OP_A:
+            big = r.reshape(-1, dim)[tv].copy()
+            big[~mv] = 0.0
+            out = np.zeros((fp.n_nodes_v, dim))
+            out[tv[mv]] = sn.vcycle(which, big.reshape(-1)).reshape(-1, dim)[mv]
+            return out.reshape(-1)
+        big = r[tp].copy()
+        big[~mp] = 0.0
+        out = np.zeros(fp.n_nodes_p)
+        out[tp[mp]] = sn.vcycle(which, big)[mp]
+        return out
+
+    def bt(p):
+        z = np.zeros(nu + n_p)
+        z[nu:] = p
+        return sp_.vmult(capi.OP_BT, z)[:nu]
+
+    def prec(src, vc):
+        p = -vc(capi.OP_MASS, src[nu:])
+        return np.concatenate([vc(capi.OP_A, src[:nu] - bt(p)), p])
+
+    rng = np.random.Generator(np.random.PCG64(1))
+    x = rng.uniform(-1, 1, nu + n_p)
+    x[:nu][fp.constrained_dofs_v()] = 0.0
+    a, b = prec(x, sp_.vcycle), sp_.precondition(x)
+    assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(b)
+
+    def gmres_iterations(vc, tol_abs, restart=100):
+        rhs = np.concatenate([pp.rhs_u, pp.rhs_p])
+        r = rhs - sp_.vmult(capi.OP_STOKES, np.concatenate([np.zeros(nu), pp.p0]))
+        rho = np.linalg.norm(r)
+        V, H, g = [r / rho], np.zeros((restart + 1, restart)), np.zeros(restart + 1)
+        g[0] = rho
+        cs, sn_ = np.zeros(restart), np.zeros(restart)
+        for j in range(restart):
+            w = sp_.vmult(capi.OP_STOKES, prec(V[j], vc))
+            for _ in range(2):
+                for i in range(j + 1):
+                    h = V[i] @ w
+                    H[i, j] += h
+                    w -= h * V[i]
+            H[j + 1, j] = np.linalg.norm(w)
+            V.append(w / H[j + 1, j])
+            for i in range(j):
+                t = cs[i] * H[i, j] + sn_[i] * H[i + 1, j]
+                H[i + 1, j] = -sn_[i] * H[i, j] + cs[i] * H[i + 1, j]
+                H[i, j] = t
+            d = np.hypot(H[j, j], H[j + 1, j])
+            cs[j], sn_[j] = H[j, j] / d, H[j + 1, j] / d
+            g[j + 1] = -sn_[j] * g[j]
+            if abs(g[j + 1]) <= tol_abs:
+                return j + 1
+        return restart
+
+    _, rep, rc = sp_.solve()
+    assert rc == 0 and rep.n_cheap_iterations == 11
+    assert gmres_iterations(sp_.vcycle, rep.solver_tolerance) == 11          # the restated solver is the oracle's
+    its = gmres_iterations(vcycle_non, rep.solver_tolerance)
+    sp_.close()
+    sn.close()
+    assert 30 <= its <= 60, its                                             # (39 when written; the reference: 53)
+
+
 def test_periodic_box_free_slip_a_block_is_singular_on_every_level():
     """Why the 53+0 of tests/periodic_box_gmg is not a number a restatement can be pinned on:
     with periodicity in x and free slip on top and bottom the x-translation is in the kernel of the A
