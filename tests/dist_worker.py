@@ -51,6 +51,8 @@ def global_problem(case, world, build=True):
         p = cases.nsinker_box(3, n_sinkers=4, ratio=1e4)
     elif case == "box3d_r3":
         p = cases.convection_box(3, 3)
+    elif case == "box3d_r4":      # BASELINE configs[4] in small: one r4 cube per rank
+        p = cases.convection_box(3, 4)
     elif case == "shell":         # BASELINE configs[3]: 96 trees of the spherical shell over the ranks
         return cases.nsinker_shell(1, n_cheap=40).build()
     else:
@@ -164,6 +166,8 @@ def main():
         check("shell residual reduction", float(hg[n - 1] / hg[0]), 0.2)
         lo_, go_ = fin.owned_dofs_v()
         check("shell iterate", relerr(xg[:fin.n_owned_nodes_v * fin.dim], xo[go_]), 1e-5)
+    if what == "vmult" and ranks.rank == 0:
+        print(f"[dist] {case} world={ranks.world} backend={backend}: level operators, Stokes and B^T (exchanges {tr.n_exchange})", flush=True)
     if what == "ops" and ranks.rank == 0:
         print(f"[dist] {case} world={ranks.world} backend={backend}: operators, transfers, V-cycles, preconditioner "
               f"(exchanges {tr.n_exchange}, all-reduces {tr.n_allreduce})", flush=True)

@@ -70,12 +70,14 @@ def test_world_size_2_gloo_partition_and_transport():
                                              (2, "nsinker_r3", "gloo"), (2, "nsinker_r3", "gloo-dev"), (4, "box3d_r3", "gloo-dev"),
                                              # rank-local set-up: every rank generates only its own subdomain
                                              (2, "nsinker_r3_ranklocal", "gloo-dev"), (8, "box3d_ranklocal", "gloo"),
+                                             # configs[4] in small (one r4 cube per rank, per-q viscosity), rank-local set-up
+                                             (2, "box3d_r4_ranklocal", "gloo-dev"), (8, "box3d_r4_ranklocal", "gloo"),
                                              # device-pointer protocol of the communicator (what RCCL uses)
                                              (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
 def test_distributed_hip_matches_serial_oracle(nproc, case, wire):
     # (the shell's iteration count to the deck's tolerance is not pinned on this geometry, tests/test_oracle_goldens.py:
     # everything up to the preconditioner is compared, then 40 iterations of the solve against the oracle's)
-    what = "ops" if case == "shell" else "all"
+    what = "ops" if case == "shell" else ("vmult" if (case, nproc) == ("box3d_r4_ranklocal", 8) else "all")
     out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, wire, what], 29550 + nproc)
     assert "[dist]" in out
 
