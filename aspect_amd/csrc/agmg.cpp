@@ -320,6 +320,7 @@ struct agmg_ctx {
   // cubes; AGMG_BRICKS=0: none.
   int use_bricks = 2;       // 0 off, 1 every level that qualifies, 2 large levels only
   int brick_z_override = 0; // AGMG_BRICK_Z: layers per brick (1, 2, 4 or 8) instead of the size-based choice
+  int brick_stack_override = 0; // AGMG_BRICK_STACK: cubes per brick along z (1, 2 or 4) instead of the size-based choice
   bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && !dist(); }
   int ensure_workspace();
   int ensure_transfers();
@@ -641,11 +642,51 @@ int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std
   }
   const int n_cubes = (int)(cube_cells.size() / 512);
   if ((size_t)n_cubes * 512 != (size_t)n) return 0;   // some cube is incomplete
-  // layers per brick: enough bricks to fill the chip on small levels, whole cubes on large ones
+  // layers per brick: enough bricks to fill the chip on small levels, whole cubes on large ones, and on very large
+  // ones STACKS of S cubes along z (a brick of 8 S layers has no partial sums on the cube faces inside it, and its
+  // prologue and top plane are paid once per 8 S layers), where every cube sits in a complete stack and enough bricks
+  // remain to keep the 512 workgroup slots of the chip in balance
   int Z = 8;
   if (n_cubes < 512) { Z = 1; while (Z < 8 && n_cubes * 8 / (2 * Z) >= 512) Z *= 2; }
   if (brick_z_override == 1 || brick_z_override == 2 || brick_z_override == 4 || brick_z_override == 8) Z = brick_z_override;
-  const int per_cube = 8 / Z, nb = n_cubes * per_cube;
+  else if (brick_stack_override == 1 || brick_stack_override == 2 || brick_stack_override == 4) Z = 8;   // (stacks are made of whole cubes)
+  const auto key_of = [](uint64_t region_, uint64_t cx, uint64_t cy, uint64_t cz) { return (region_ << 42) | (cz << 28) | (cy << 14) | cx; };
+  std::vector<std::array<int32_t, 4>> cube_pos(n_cubes);     // (region, cx, cy, cz) of every cube
+  for (const auto &kv : cube_of)
+    cube_pos[kv.second] = {(int32_t)(kv.first >> 42), (int32_t)(kv.first & 0x3FFF), (int32_t)((kv.first >> 14) & 0x3FFF), (int32_t)((kv.first >> 28) & 0x3FFF)};
+  const auto stackable = [&](int S_) {
+    if (n_cubes % S_) return false;
+    for (int cube = 0; cube < n_cubes; ++cube) {
+      const auto &q = cube_pos[cube];
+      const int base = q[3] - q[3] % S_;
+      for (int s_ = 0; s_ < S_; ++s_)
+        if (!cube_of.count(key_of(q[0], q[1], q[2], base + s_))) return false;
+    }
+    return true;
+  };
+  int S = 1;
+  if (Z == 8) {
+    if (brick_stack_override == 1 || brick_stack_override == 2 || brick_stack_override == 4) {
+      if (stackable(brick_stack_override)) S = brick_stack_override;
+    } else {
+      // (measured at r7 = 4096 cubes: 763 us per A-block vmult with one cube per brick, 744 with two, 751 with four:
+      // fewer, longer bricks save partial sums but balance worse over the 512 workgroup slots)
+      if (n_cubes / 4 >= 4096 && stackable(4)) S = 4;
+      else if (n_cubes / 2 >= 1024 && stackable(2)) S = 2;
+    }
+  }
+  // bricks in the order of their first cube; stack_cubes[brick][s] = the cube of layers 8 s .. 8 s + 7
+  std::vector<int32_t> stack_cubes;
+  if (S > 1) {
+    for (int cube = 0; cube < n_cubes; ++cube) {
+      const auto &q = cube_pos[cube];
+      if (q[3] % S) continue;
+      for (int s_ = 0; s_ < S; ++s_) stack_cubes.push_back(cube_of.at(key_of(q[0], q[1], q[2], q[3] + s_)));
+    }
+    if ((int)stack_cubes.size() != n_cubes) return 0;
+    Z = 8 * S;
+  }
+  const int per_cube = S > 1 ? 1 : 8 / Z, nb = S > 1 ? n_cubes / S : n_cubes * per_cube;
   const int nplanes = 2 * Z + 1, latn = BRICK_PLANE * nplanes;
   if ((uint64_t)nb * latn > 0xFFFFFFFFull) return 0;
   // surface enumeration of the lattice
@@ -658,14 +699,16 @@ int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std
           pidx[(size_t)K * BRICK_PLANE + J * BRICK_LAT + I] = (uint16_t)npb++;
   if ((uint64_t)nb * npb > 0xFFFFFFFFull) return 0;
   std::vector<uint32_t> gnode((size_t)nb * latn, 0xFFFFFFFFu), bcell((size_t)nb * Z * 64);
-  for (int cube = 0; cube < n_cubes; ++cube)
+  for (int first = 0; first < (S > 1 ? nb : n_cubes); ++first)
     for (int sub = 0; sub < per_cube; ++sub) {
-      const int brick = cube * per_cube + sub;
+      const int brick = first * per_cube + sub;
       uint32_t *lat = &gnode[(size_t)brick * latn];
       for (int kl = 0; kl < Z; ++kl)
         for (int jj = 0; jj < 8; ++jj)
           for (int ii = 0; ii < 8; ++ii) {
-            const int cell = cube_cells[(size_t)cube * 512 + (sub * Z + kl) * 64 + jj * 8 + ii];
+            const int cube = S > 1 ? stack_cubes[(size_t)first * S + kl / 8] : first;
+            const int layer = S > 1 ? kl % 8 : sub * Z + kl;
+            const int cell = cube_cells[(size_t)cube * 512 + layer * 64 + jj * 8 + ii];
             bcell[((size_t)brick * Z + kl) * 64 + jj * 8 + ii] = (uint32_t)cell;
             for (int a = 0; a < 27; ++a) {
               const int ax = a % 3, ay = (a / 3) % 3, az = a / 9;
@@ -2095,6 +2138,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (const char *e = getenv("AGMG_NO_BLOCKS")) c->use_blocks = atoi(e) == 0;
   if (const char *e = getenv("AGMG_BRICKS")) c->use_bricks = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("AGMG_BRICK_Z")) c->brick_z_override = atoi(e);
+  if (const char *e = getenv("AGMG_BRICK_STACK")) c->brick_stack_override = atoi(e);
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
   if (const char *e = getenv("AGMG_GRAPHS")) c->use_graphs = atoi(e) != 0;

@@ -152,24 +152,11 @@ template <int DIM> struct WaveXch {
     __builtin_amdgcn_wave_barrier();
   }
 };
-// BrickXch: one wavefront per component, lane = cell (kernels_brick.hip).  Two tiles
-// [3 x][3 comp][3 dir][64] used alternately line by line, so one workgroup barrier per line is
-// enough: a tile is rewritten two lines later, behind the barrier of the line in between, which
-// every wave only reaches with its reads of this line done.
-struct BrickXch {
-  static constexpr int TILE = 27 * 64;   // doubles per tile
-  double *buf;       // two tiles
-  int lane, wpar, rpar;   // tile the next puts go to / the gets come from
-  __device__ __forceinline__ void put(int x, int c, int dd, double v) const { buf[wpar * TILE + ((x * 3 + c) * 3 + dd) * 64 + lane] = v; }
-  __device__ __forceinline__ double get(int x, int from, int dir) const { return buf[rpar * TILE + ((x * 3 + from) * 3 + dir) * 64 + lane]; }
-  __device__ __forceinline__ void publish() { __syncthreads(); wpar ^= 1; }
-  __device__ __forceinline__ void release() { rpar ^= 1; }
-};
 
 // One cell per DIM lanes: gather, sum-factorised evaluate, q-point operation, integrate.
 // Lane (j, c) handles component c of cell `cell`; G receives the 3^DIM velocity
 // contributions of that component, pout this lane's share of the 2^DIM pressure rows (Stokes).
-// ex: the exchange of the velocity gradient between the lanes of a cell (WaveXch / BrickXch).
+// ex: the exchange of the velocity gradient between the lanes of a cell (WaveXch).
 // eta_tile (ETA_LDS): wave-private LDS copy [q][CPW] of the per-q viscosities of the wave's cells.
 // GATHER: read the cell's velocity values from global memory here; otherwise the caller has
 // filled u[] (the block kernel gathers from an LDS copy of the block's nodes).

@@ -597,6 +597,48 @@ def test_brick_kernels_layers_per_brick(case, layers, hip_lib, oracle_lib, monke
         g.close(); o.close()
 
 
+@pytest.mark.parametrize("case,stack,want", [
+    ("box_r4", 2, (4, 16)),            # 2 x 2 x 2 cubes -> 4 bricks of 16 layers
+    ("nsinker_r4", 1, (8, 8)),         # the same cubes, one per brick
+    ("box_r3_trees_1x1x4", 4, (1, 32)),  # four trees of one cube each, stacked along z: one brick of 32 layers
+    ("box_r3_trees_1x1x4", 2, (2, 16)),
+    ("box_r3_trees_1x1x3", 2, (3, 8)),   # three cubes do not fill stacks of two: one cube per brick
+])
+def test_brick_stacks_along_z(case, stack, want, hip_lib, oracle_lib, monkeypatch):
+    """Bricks of several cubes stacked along z (AGMG_BRICK_STACK; by default from 4096 cubes on): no partial sums on
+    the cube faces inside a brick.  A block with store / residual / Chebyshev epilogues (V-cycle) against the oracle,
+    per-q and cell-constant viscosity, stacks across tree boundaries, and the fall-back when the cubes of a column
+    do not fill whole stacks."""
+    monkeypatch.setenv("AGMG_BRICKS", "1")
+    monkeypatch.setenv("AGMG_BRICK_STACK", str(stack))
+    if case == "box_r4":
+        p = cases.convection_box(3, 4)
+    elif case == "nsinker_r4":
+        p = cases.nsinker_box(4, n_sinkers=4, ratio=1e4)
+    else:
+        nz = int(case[-1])
+        p = cases.nsinker_box(3, n_sinkers=4, ratio=1e4)
+        p.reps, p.extents = [1, 1, nz], [1.0, 1.0, float(nz)]
+    p.build()
+    g, o = capi.Solver(hip_lib, p), capi.Solver(oracle_lib, p)
+    fin = p.hier.finest
+    try:
+        assert g.kernel_path()[:2] == want
+        for level in (capi.ACTIVE, p.hier.n_levels - 1):
+            src = rand_vec(g.size(capi.OP_A, level), 131, fin, zero_constrained=False)
+            assert relerr(g.vmult(capi.OP_A, src, level), o.vmult(capi.OP_A, src, level)) < RTOL, level
+        a = g.vmult(capi.OP_A, src)
+        assert np.array_equal(a, g.vmult(capi.OP_A, src))                  # bitwise reproducible
+        for s in (g, o):
+            s.setup_smoothers()
+        src = rand_vec(g.size(capi.OP_A), 117, fin)
+        assert relerr(g.vcycle(capi.OP_A, src), o.vcycle(capi.OP_A, src)) < 1e-9
+        src = rand_vec(g.size(capi.OP_STOKES), 118, fin)
+        assert relerr(g.precondition(src), o.precondition(src)) < 1e-9
+    finally:
+        g.close(); o.close()
+
+
 def test_brick_kernels_equal_block_kernels(hip_lib, monkeypatch):
     """Same operator through the brick path (AGMG_BRICKS=1) and through the block path."""
     p = cases.nsinker_box(4, n_sinkers=4, ratio=1e4, averaging=bm.AVG_NONE)
