@@ -54,6 +54,10 @@ class LevelDesc(C.Structure):
         ("send_offsets_v", c_i32p), ("send_nodes_v", c_u32p), ("recv_offsets_v", c_i32p),
         ("send_offsets_p", c_i32p), ("send_nodes_p", c_u32p), ("recv_offsets_p", c_i32p),
         ("global_nodes_v", c_u32p), ("global_nodes_p", c_u32p),
+        ("n_hanging_v", C.c_int32), ("n_hanging_p", C.c_int32),
+        ("hanging_nodes_v", c_u32p), ("hanging_ptr_v", c_i32p), ("hanging_master_v", c_u32p), ("hanging_weight_v", c_dp),
+        ("hanging_nodes_p", c_u32p), ("hanging_ptr_p", c_i32p), ("hanging_master_p", c_u32p), ("hanging_weight_p", c_dp),
+        ("refinement_edge_v", c_u8p), ("refinement_edge_p", c_u8p),
     ]
 
 
@@ -282,6 +286,17 @@ class Solver:
             d.send_offsets_p, d.send_nodes_p, d.recv_offsets_p = _ptr(plan[3], C.c_int32), _ptr(plan[4], C.c_uint32), _ptr(plan[5], C.c_int32)
             d.global_nodes_v, d.global_nodes_p = _ptr(plan[6], C.c_uint32), _ptr(plan[7], C.c_uint32)
             keep += [nb] + plan
+        if getattr(lev, "hanging_v", None) is not None:
+            # hanging-node constraints of an adaptive mesh: (nodes, ptr, masters, weights) per space
+            for name, (hn, hp, hm, hw) in (("v", lev.hanging_v), ("p", lev.hanging_p)):
+                arrs = [np.ascontiguousarray(hn, dtype=np.uint32), np.ascontiguousarray(hp, dtype=np.int32),
+                        np.ascontiguousarray(hm, dtype=np.uint32), np.ascontiguousarray(hw, dtype=np.float64)]
+                setattr(d, "n_hanging_" + name, arrs[0].size)
+                setattr(d, "hanging_nodes_" + name, _ptr(arrs[0], C.c_uint32))
+                setattr(d, "hanging_ptr_" + name, _ptr(arrs[1], C.c_int32))
+                setattr(d, "hanging_master_" + name, _ptr(arrs[2], C.c_uint32))
+                setattr(d, "hanging_weight_" + name, _ptr(arrs[3], C.c_double))
+                keep += arrs
         if l > 0 and lev.level > 0:
             nch = 1 << lev.dim
             par = (np.arange(lev.n_cells, dtype=np.int32) // nch).astype(np.int32)

@@ -48,6 +48,13 @@ struct HostLevel {  // host copies kept for building the transfer tables
   std::vector<uint32_t> cnv, cnp;
   std::vector<int32_t> parent;
   std::vector<uint8_t> child;
+  // hanging-node constraints (agmg_level_desc; first slice: resolved on the host around agmg_vmult): CSR over the
+  // hanging nodes of the velocity [0] and pressure [1] spaces, and the constraint masks of the two spaces
+  std::vector<uint32_t> hang_n[2], hang_m[2];
+  std::vector<int32_t> hang_ptr[2];
+  std::vector<double> hang_w[2];
+  std::vector<uint8_t> cmask[2];
+  bool has_hanging() const { return !hang_n[0].empty() || !hang_n[1].empty(); }
 };
 
 struct Smoother {  // PreconditionChebyshev state
@@ -143,6 +150,7 @@ struct agmg_ctx {
   hipStream_t stream = nullptr;
   std::vector<DeviceLevel> L;
   std::vector<HostLevel> H;
+  bool has_hanging() const { for (const auto &h : H) if (h.has_hanging()) return true; return false; }
   CoeffData active;
   FaceTerm faces;   // free-surface stabilisation faces of the active Stokes operator
   void free_faces() {
@@ -2273,6 +2281,24 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   const uint8_t vmask = (uint8_t)((1u << dim) - 1u);
   for (auto &m : cmv) m &= vmask;
   for (auto &m : cmp) m &= 1u;
+  for (int sp = 0; sp < 2; ++sp) {   // hanging-node constraints (first slice: one-level contexts, host-vector operators)
+    const int nh = sp == 0 ? d->n_hanging_v : d->n_hanging_p, nn = sp == 0 ? lv.n_nodes_v : lv.n_nodes_p;
+    const uint32_t *hn = sp == 0 ? d->hanging_nodes_v : d->hanging_nodes_p, *hm = sp == 0 ? d->hanging_master_v : d->hanging_master_p;
+    const int32_t *hp = sp == 0 ? d->hanging_ptr_v : d->hanging_ptr_p;
+    const double *hw = sp == 0 ? d->hanging_weight_v : d->hanging_weight_p;
+    hl.hang_n[sp].clear(); hl.hang_m[sp].clear(); hl.hang_ptr[sp].clear(); hl.hang_w[sp].clear();
+    hl.cmask[sp] = sp == 0 ? cmv : cmp;
+    if (nh <= 0) continue;
+    if (c->nl() != 1 || c->dist()) { set_error("hanging-node constraints: one-level, one-rank contexts only (first slice; SURVEY.md 8 f1)"); return -2; }
+    if (!hn || !hp || !hm || !hw) { set_error("incomplete hanging-node tables"); return -1; }
+    if (hp[0] != 0) { set_error("hanging_ptr must start at 0"); return -1; }
+    for (int i = 0; i < nh; ++i) if (hp[i + 1] < hp[i]) { set_error("hanging_ptr must be non-decreasing"); return -1; }
+    hl.hang_n[sp].assign(hn, hn + nh); hl.hang_ptr[sp].assign(hp, hp + nh + 1);
+    hl.hang_m[sp].assign(hm, hm + hp[nh]); hl.hang_w[sp].assign(hw, hw + hp[nh]);
+    std::vector<uint8_t> is_h(nn, 0);
+    for (uint32_t h : hl.hang_n[sp]) { if ((int)h >= nn) { set_error("hanging node out of range"); return -1; } is_h[h] = 1; }
+    for (uint32_t m : hl.hang_m[sp]) if ((int)m >= nn || is_h[m]) { set_error("hanging-node master out of range or hanging itself"); return -1; }
+  }
   lv.n_owned_v = lv.n_nodes_v; lv.n_owned_p = lv.n_nodes_p;
   for (int w = 0; w < 2; ++w) c->send_nodes_h[w][level].clear();
   if (has_plan) {  // ghost exchange plans of the two node spaces
@@ -2651,6 +2677,7 @@ int agmg_set_free_surface_faces(agmg_ctx *c, const agmg_face_data *d) {
 
 int agmg_compute_diagonals(agmg_ctx *c) {
   if (!c) { set_error("null context"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_compute_diagonals: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   for (auto &l : c->L) if (!l.set || !l.coeff.set) { set_error("compute_diagonals: every level needs tables and coefficients"); return -1; }
   CHECK(c->ensure_workspace());
@@ -2728,6 +2755,7 @@ static int vmult_device_impl(agmg_ctx *c, int which, int level, double *dst, con
 
 int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const double *src) {
   if (!c) { set_error("null context"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_vmult_device: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
@@ -2742,6 +2770,7 @@ int agmg_vmult_device(agmg_ctx *c, int which, int level, double *dst, const doub
 // at zero).  Calls that overlap on one GPU share the array and race.
 int agmg_vmult_device_noalloc(agmg_ctx *c, int which, int level, double *dst, const double *src) {
   if (!c) { set_error("null context"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_vmult_device_noalloc: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   if (!dst || !src) { set_error("null vector"); return -1; }
   if (c->dist()) { set_error("agmg_vmult_device_noalloc: one-rank contexts only (the ghost exchange stages through buffers it allocates)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
@@ -2779,11 +2808,60 @@ int agmg_vmult_device_noalloc(agmg_ctx *c, int which, int level, double *dst, co
   return rc;
 }
 
+// Hanging-node constraints around a device operator that treats every node as its own DoF (what MatrixFree's
+// read_dof_values / distribute_local_to_global do with AffineConstraints; constrained rows are identity rows):
+// y = C^T A C x.  Masters with a homogeneous Dirichlet bit contribute zero and receive nothing.  Host vectors.
+static int vmult_hanging_host(agmg_ctx *c, int which, int level, double *dst, const double *src, size_t n) {
+  const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
+  const HostLevel &hl = c->H[l];
+  const DeviceLevel &lv = c->L[l];
+  const int dim = lv.dim;
+  const bool has_u = which != AGMG_OP_MASS, has_p = which != AGMG_OP_A;
+  const size_t poff = has_u ? lv.n_dofs_v() : 0;
+  std::vector<double> xs(src, src + n), ys(n);
+  auto con = [&](int sp, uint32_t node, int comp) { return sp == 0 ? ((hl.cmask[0][node] >> comp) & 1) != 0 : (hl.cmask[1][node] & 1) != 0; };
+  auto resolve = [&](int sp, size_t off, int nc) {
+    for (size_t i = 0; i < hl.hang_n[sp].size(); ++i)
+      for (int comp = 0; comp < nc; ++comp) {
+        double v = 0;
+        for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k)
+          if (!con(sp, hl.hang_m[sp][k], comp)) v += hl.hang_w[sp][k] * src[off + (size_t)hl.hang_m[sp][k] * nc + comp];
+        xs[off + (size_t)hl.hang_n[sp][i] * nc + comp] = v;
+      }
+  };
+  auto distribute = [&](int sp, size_t off, int nc) {
+    for (size_t i = 0; i < hl.hang_n[sp].size(); ++i) {
+      const uint32_t h = hl.hang_n[sp][i];
+      for (int comp = 0; comp < nc; ++comp) {
+        if (!con(sp, h, comp))
+          for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k)
+            if (!con(sp, hl.hang_m[sp][k], comp)) ys[off + (size_t)hl.hang_m[sp][k] * nc + comp] += hl.hang_w[sp][k] * ys[off + (size_t)h * nc + comp];
+        ys[off + (size_t)h * nc + comp] = src[off + (size_t)h * nc + comp];
+      }
+    }
+  };
+  if (has_u) resolve(0, 0, dim);
+  if (has_p) resolve(1, poff, 1);
+  double *ds, *dd;
+  CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
+  int rc = c->h2d(ds, xs.data(), n);
+  if (!rc) rc = c->ensure_workspace();
+  if (!rc) rc = vmult_device_impl(c, which, level, dd, ds);
+  if (!rc) rc = c->d2h(ys.data(), dd, n);
+  c->dfree(ds); c->dfree(dd);
+  if (rc) return rc;
+  if (has_u) distribute(0, 0, dim);
+  if (which == AGMG_OP_MASS || which == AGMG_OP_STOKES) distribute(1, poff, 1);   // (B^T writes no pressure rows)
+  std::copy(ys.begin(), ys.end(), dst);
+  return 0;
+}
+
 int agmg_vmult(agmg_ctx *c, int which, int level, double *dst, const double *src) {
   if (!c) { set_error("null context"); return -1; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
+  if (c->has_hanging()) return vmult_hanging_host(c, which, level, dst, src, n);
   double *ds, *dd;
   CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
   int rc = c->h2d(ds, src, n);
@@ -2796,6 +2874,7 @@ int agmg_vmult(agmg_ctx *c, int which, int level, double *dst, const double *src
 // correct_stokes_rhs (local_smoothing.cc:761-898): rhs += -M u0, u0 read without the constraints
 int agmg_rhs_correction(agmg_ctx *c, const double *u0_h, double *rhs_h) {
   if (!c || !u0_h || !rhs_h) { set_error("null argument"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_rhs_correction: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   const DeviceLevel &lv = c->fin();
   if (!lv.set || !c->active_coeff().set) { set_error("rhs_correction: active mesh tables / coefficients not set"); return -1; }
@@ -2844,6 +2923,7 @@ int agmg_rhs_correction(agmg_ctx *c, const double *u0_h, double *rhs_h) {
 
 int agmg_get_inverse_diagonal(agmg_ctx *c, int which, int level, double *dst) {
   if (!c || level < 0 || level >= c->nl()) { set_error("bad level"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_get_inverse_diagonal: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   if (!c->diag_ready) { set_error("diagonals not computed"); return -1; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   const DeviceLevel &lv = c->L[level];
@@ -2888,12 +2968,16 @@ int agmg_restrict_add(agmg_ctx *c, int which, int from_level, double *dst, const
 
 int agmg_setup_smoothers(agmg_ctx *c) {
   if (!c) { set_error("null context"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_setup_smoothers: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
+  if (c->has_hanging()) { set_error("agmg_restrict_add: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
+  if (c->has_hanging()) { set_error("agmg_prolongate_add: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   return c->setup_smoothers();
 }
 
 int agmg_get_eigenvalue_estimates(agmg_ctx *c, int which, int level, double *lmin, double *lmax) {
   if (!c || level < 0 || level >= c->nl() || !c->smoothers_ready) { set_error("smoothers not set up"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_get_eigenvalue_estimates: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   const Smoother &s = c->sm[which == AGMG_OP_A ? 0 : 1][level];
   *lmin = s.lmin; *lmax = s.lmax;
   return 0;
@@ -2901,6 +2985,7 @@ int agmg_get_eigenvalue_estimates(agmg_ctx *c, int which, int level, double *lmi
 
 int agmg_vcycle(agmg_ctx *c, int which, double *dst, const double *src) {
   if (!c) { set_error("null context"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_vcycle: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   if (which != AGMG_OP_A && which != AGMG_OP_MASS) { set_error("vcycle: which must be A or MASS"); return -1; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   if (!c->smoothers_ready) CHECK(c->setup_smoothers());
@@ -2917,6 +3002,7 @@ int agmg_vcycle(agmg_ctx *c, int which, double *dst, const double *src) {
 
 int agmg_precondition(agmg_ctx *c, int expensive, double *dst, const double *src) {
   if (!c) { set_error("null context"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_precondition: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   if (!c->smoothers_ready) CHECK(c->setup_smoothers());
   const size_t n = (size_t)c->fin().n_dofs_v() + c->fin().n_dofs_p();
@@ -2933,6 +3019,7 @@ int agmg_precondition(agmg_ctx *c, int expensive, double *dst, const double *src
 
 int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_solve_report *rep) {
   if (!c || !rhs_h || !x_h || !rep) { set_error("null argument"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_solve: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   std::memset(rep, 0, sizeof(*rep));
   rep->initial_nonlinear_residual = rep->final_linear_residual = std::numeric_limits<double>::quiet_NaN();
@@ -3011,6 +3098,7 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
 
 int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *seconds_per_vmult) {
   if (!c || n_repeat < 1 || !seconds_per_vmult) { set_error("bad argument"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_bench_vmult: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
@@ -3049,6 +3137,7 @@ int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *se
 // smoothers (eigenvalue estimates of every level, what the reference redoes in every solve()).
 int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
   if (!c || !seconds || n_repeat < 1) { set_error("bad argument"); return -1; }
+  if (c->has_hanging()) { set_error("agmg_execute_solver_timings: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   {
     CHECK(c->sync());

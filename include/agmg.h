@@ -148,6 +148,22 @@ typedef struct agmg_level_desc {
    * (SURVEY.md A.5), so that it does not depend on the partition. */
   const uint32_t *global_nodes_v; /* [n_nodes_v] */
   const uint32_t *global_nodes_p; /* [n_nodes_p] */
+  /* Hanging-node constraints of an adaptively refined mesh (what AffineConstraints holds after
+   * DoFTools::make_hanging_node_constraints, local_smoothing.cc:1597-1605, and what MatrixFree resolves
+   * in read_dof_values / distribute_local_to_global): CSR over the hanging nodes, node h =
+   * hanging_nodes_x[i] takes the value sum_k hanging_weight_x[k] * node hanging_master_x[k],
+   * k in [hanging_ptr_x[i], hanging_ptr_x[i+1]); all components of a velocity node share the weights;
+   * masters are not hanging themselves.  n_hanging_x == 0 (and NULL tables): none.
+   * FIRST SLICE: accepted on one-level contexts (n_levels == 1: an adaptive active mesh on its own) and
+   * resolved around the operators of the host-vector entry point agmg_vmult; every other entry point
+   * of a context that holds such a level returns status -2.  The edge masks are what the level
+   * operators of local smoothing need (MGConstrainedDoFs::get_refinement_edge_indices, :1804-1813;
+   * vmult_interface_down / _up): carried, not used yet. */
+  int32_t n_hanging_v, n_hanging_p;
+  const uint32_t *hanging_nodes_v; const int32_t *hanging_ptr_v; const uint32_t *hanging_master_v; const double *hanging_weight_v;
+  const uint32_t *hanging_nodes_p; const int32_t *hanging_ptr_p; const uint32_t *hanging_master_p; const double *hanging_weight_p;
+  const uint8_t *refinement_edge_v;  /* [n_nodes_v] 1: node on the refinement edge of this level, or NULL */
+  const uint8_t *refinement_edge_p;  /* [n_nodes_p] or NULL */
 } agmg_level_desc;
 
 /* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */

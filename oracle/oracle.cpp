@@ -141,6 +141,11 @@ struct Level {
   std::vector<uint8_t> child;
   CellData cd;
   Vec inv_diag_A, inv_diag_M, diag_M;
+  // hanging-node constraints (agmg_level_desc): CSR over the hanging nodes of the two spaces
+  std::vector<uint32_t> hang_n[2], hang_m[2];     // [0] velocity nodes, [1] pressure nodes
+  std::vector<int32_t> hang_ptr[2];
+  Vec hang_w[2];
+  bool has_hanging() const { return !hang_n[0].empty() || !hang_n[1].empty(); }
   bool set = false;
   int ndv() const { return dim * n_nodes_v; }
   int ndp() const { return n_nodes_p; }
@@ -1565,6 +1570,21 @@ int oracle_set_level(oracle_ctx *o, int level, const agmg_level_desc *d) {
     L.parent.assign(d->parent_cell, d->parent_cell + L.n_cells);
     L.child.assign(d->child_index, d->child_index + L.n_cells);
   }
+  for (int sp = 0; sp < 2; ++sp) {
+    const int nh = sp == 0 ? d->n_hanging_v : d->n_hanging_p, nn = sp == 0 ? L.n_nodes_v : L.n_nodes_p;
+    const uint32_t *hn = sp == 0 ? d->hanging_nodes_v : d->hanging_nodes_p, *hm = sp == 0 ? d->hanging_master_v : d->hanging_master_p;
+    const int32_t *hp = sp == 0 ? d->hanging_ptr_v : d->hanging_ptr_p;
+    const double *hw = sp == 0 ? d->hanging_weight_v : d->hanging_weight_p;
+    L.hang_n[sp].clear(); L.hang_m[sp].clear(); L.hang_ptr[sp].clear(); L.hang_w[sp].clear();
+    if (nh <= 0) continue;
+    if (C.levels.size() != 1) { g_error = "hanging-node constraints: one-level contexts only (first slice)"; return -2; }
+    if (!hn || !hp || !hm || !hw) { g_error = "incomplete hanging-node tables"; return -1; }
+    L.hang_n[sp].assign(hn, hn + nh); L.hang_ptr[sp].assign(hp, hp + nh + 1);
+    L.hang_m[sp].assign(hm, hm + hp[nh]); L.hang_w[sp].assign(hw, hw + hp[nh]);
+    std::vector<uint8_t> is_h(nn, 0);
+    for (uint32_t h : L.hang_n[sp]) { if (int(h) >= nn) { g_error = "hanging node out of range"; return -1; } is_h[h] = 1; }
+    for (uint32_t m : L.hang_m[sp]) if (int(m) >= nn || is_h[m]) { g_error = "hanging-node master out of range or hanging itself"; return -1; }
+  }
   for (size_t i = 0; i < L.cnv.size(); ++i) if (int(L.cnv[i]) >= L.n_nodes_v) { g_error = "cell_nodes_v out of range"; return -1; }
   for (size_t i = 0; i < L.cnp.size(); ++i) if (int(L.cnp[i]) >= L.n_nodes_p) { g_error = "cell_nodes_p out of range"; return -1; }
   L.set = true;
@@ -1636,10 +1656,65 @@ int oracle_compute_diagonals(oracle_ctx *o) {
   return 0;
 }
 
+static void vmult_impl(Ctx &C, int which, int level, double *dst, const double *src, bool dense);
+
+// MatrixFree's treatment of hanging-node constraints around an operator that treats every node as its own DoF
+// (read_dof_values resolves the constraints, distribute_local_to_global applies their transpose, constrained rows are
+// identity rows): y = C^T A C x on the unconstrained DoFs.  Masters with a homogeneous Dirichlet bit contribute zero and
+// receive nothing (AffineConstraints merges the two kinds of constraints that way).
+static void vmult_hanging(Ctx &C, int which, int level, double *dst, const double *src, bool dense) {
+  Level &L = const_cast<Level &>(level == AGMG_ACTIVE ? C.fin() : C.levels[level]);
+  const int dim = L.dim, nu = L.ndv(), np_ = L.ndp();
+  const bool has_u = which != AGMG_OP_MASS, has_p = which != AGMG_OP_A;
+  const size_t n = (has_u ? size_t(nu) : 0) + (has_p ? size_t(np_) : 0);     // A: u; mass: p; Stokes, B^T: [u; p]
+  Vec xs(src, src + n), ys(n, 0.0);
+  const size_t poff = has_u ? nu : 0;                        // offset of the pressure block in the vector
+  auto resolve = [&](int sp, size_t off, int nc) {
+    for (size_t i = 0; i < L.hang_n[sp].size(); ++i) {
+      const uint32_t h = L.hang_n[sp][i];
+      for (int c = 0; c < nc; ++c) {
+        double v = 0;
+        for (int k = L.hang_ptr[sp][i]; k < L.hang_ptr[sp][i + 1]; ++k) {
+          const uint32_t m = L.hang_m[sp][k];
+          const bool con = sp == 0 ? L.constrained_v(m, c) : L.constrained_p(m);
+          if (!con) v += L.hang_w[sp][k] * src[off + size_t(m) * nc + c];
+        }
+        xs[off + size_t(h) * nc + c] = v;
+      }
+    }
+  };
+  auto distribute = [&](int sp, size_t off, int nc) {
+    for (size_t i = 0; i < L.hang_n[sp].size(); ++i) {
+      const uint32_t h = L.hang_n[sp][i];
+      for (int c = 0; c < nc; ++c) {
+        const bool con_h = sp == 0 ? L.constrained_v(h, c) : L.constrained_p(h);
+        if (!con_h)
+          for (int k = L.hang_ptr[sp][i]; k < L.hang_ptr[sp][i + 1]; ++k) {
+            const uint32_t m = L.hang_m[sp][k];
+            const bool con = sp == 0 ? L.constrained_v(m, c) : L.constrained_p(m);
+            if (!con) ys[off + size_t(m) * nc + c] += L.hang_w[sp][k] * ys[off + size_t(h) * nc + c];
+          }
+        ys[off + size_t(h) * nc + c] = src[off + size_t(h) * nc + c];      // constrained row: identity
+      }
+    }
+  };
+  if (has_u) resolve(0, 0, dim);
+  if (has_p) resolve(1, poff, 1);
+  // the operator itself, on a level without the tables (every node its own DoF)
+  std::vector<uint32_t> hn[2] = {std::move(L.hang_n[0]), std::move(L.hang_n[1])};
+  L.hang_n[0].clear(); L.hang_n[1].clear();
+  vmult_impl(C, which, level, ys.data(), xs.data(), dense);
+  L.hang_n[0] = std::move(hn[0]); L.hang_n[1] = std::move(hn[1]);
+  if (has_u) distribute(0, 0, dim);
+  if (which == AGMG_OP_MASS || which == AGMG_OP_STOKES) distribute(1, poff, 1);     // (B^T writes no pressure rows)
+  std::copy(ys.begin(), ys.end(), dst);
+}
+
 static void vmult_impl(Ctx &C, int which, int level, double *dst, const double *src, bool dense) {
   const Level &L = level == AGMG_ACTIVE ? C.fin() : C.levels[level];
   const CellData &cd = level == AGMG_ACTIVE ? C.active_cd : L.cd;
   const int nu = L.ndv();
+  if (L.has_hanging()) { vmult_hanging(C, which, level, dst, src, dense); return; }
   if (dense) { if (C.opt.dim == 2) dense_vmult<2>(L, cd, which, src, dst); else dense_vmult<3>(L, cd, which, src, dst); return; }
   if (C.opt.dim == 2) {
     if (which == AGMG_OP_MASS) mass_vmult<2>(L, cd, src, dst);

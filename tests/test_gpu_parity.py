@@ -1024,3 +1024,34 @@ def test_plane_per_lane_restriction_is_bit_identical(name, hip_lib, monkeypatch)
     vb = s.vcycle(capi.OP_A, src)
     s.close()
     assert np.array_equal(va, vb)
+
+
+# ---- hanging nodes (first slice) ---------------------------------------------------------------------
+@pytest.mark.parametrize("n_second,per_q", [(0, True), (5, False)])
+def test_hanging_node_operators(n_second, per_q, hip_lib, oracle_lib):
+    """The adaptive meshes of tests/stokes (120 cells on 4 levels, 155 on 5; DoF counts pinned by the reference's
+    screen output in tests/test_oracle_goldens.py) through agmg_vmult: all four operators against the oracle to 1e-12
+    with a sinker viscosity (per quadrature point / per cell), free slip on the walls, and the entry points that do not
+    resolve the constraints yet say so with status -2."""
+    from aspect_amd import adaptivemesh as am
+    from hipmem import DeviceArray
+    from test_oracle_goldens import _stokes_adaptive_mesh
+    m = _stokes_adaptive_mesh(n_second)
+    eta = lambda x: 1.0 + 99.0 * np.exp(-40.0 * ((x - 0.5) ** 2).sum(axis=1))
+    p = am.AdaptiveProblem(m, eta, per_q=per_q, pressure_scaling=3.0)
+    g, o = capi.Solver(hip_lib, p, single_level=True), capi.Solver(oracle_lib, p, single_level=True)
+    try:
+        rng = np.random.Generator(np.random.PCG64(5))
+        for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT, capi.OP_MASS):
+            src = rng.uniform(-1, 1, g.size(which))
+            a, b = g.vmult(which, src), o.vmult(which, src)
+            assert relerr(a, b) < RTOL, which
+            assert np.array_equal(a, g.vmult(which, src))                     # reproducible
+        n = g.size(capi.OP_A)
+        d = DeviceArray(n).fill_bytes(0)
+        assert hip_lib.vmult_device(g.ctx, capi.OP_A, capi.ACTIVE, d.ptr, d.ptr) == -2
+        assert b"hanging-node" in hip_lib.last_error()
+        assert hip_lib.setup_smoothers(g.ctx) == -2
+        d.free()
+    finally:
+        g.close(); o.close()

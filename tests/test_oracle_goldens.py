@@ -849,3 +849,85 @@ def test_convection_box_phase_function_first_solve_golden():
     x, rep, rc = s.solve()
     s.close()
     assert rc == 0 and (rep.n_cheap_iterations, rep.n_expensive_iterations) == (g["solves"][0]["cheap"], 0)
+
+
+# ---- hanging nodes (first slice): adaptive active mesh, constraints resolved around the operators -------
+def _stokes_adaptive_mesh(n_second):
+    """The meshes of tests/stokes.prm: global refinement 2, the 8 cells around the sinker refined (mesh 2), then the
+    `n_second` level-3 cells closest to the centre refined once more (mesh 3; which cells the reference's velocity
+    indicator picks is not printed: the five closest reproduce its counts)."""
+    from aspect_amd import adaptivemesh as am
+
+    def marker(c, lv, r):
+        if r == 0:
+            return np.all(np.abs(c - 0.5) < 0.26, axis=1)
+        d = np.linalg.norm(c - 0.5, axis=1)
+        mark = np.zeros(len(d), dtype=bool)
+        mark[np.argsort(d + 1e-9 * np.arange(len(d)))[:n_second]] = True
+        return mark & (lv == 3)
+    return am.AdaptiveBoxLevel(3, 2, marker, rounds=2 if n_second else 1)
+
+
+def test_hanging_node_dof_counts_match_the_reference():
+    """tests/stokes/screen-output: 'Number of active cells: 120 (on 4 levels)', 4,215+223 Stokes DoFs; '155 (on 5
+    levels)', 5,631+294.  deal.II counts hanging nodes as DoFs, and where a refined line or face meets its unrefined
+    neighbour the middle vertex of the children and the coarse line / quad DoF at the same point are two DoFs (tied with
+    weight 1): 72 such pairs on the second mesh (24 faces + 48 lines of the surface of the refined 2 x 2 x 2 block)."""
+    g = G["stokes"]["meshes"]
+    m2 = _stokes_adaptive_mesh(0)
+    assert (m2.n_cells, m2.n_dofs_v, m2.n_dofs_p, m2.n_levels_of_mesh) == (g[1]["cells"], g[1]["dofs_u"], g[1]["dofs_p"], g[1]["levels"])
+    hn, hp, hm, hw = m2.hanging_v
+    assert hn.size == 360 and np.count_nonzero(np.diff(hp) == 1) == 72 and set(np.diff(hp)) == {1, 3, 9}
+    assert m2.hanging_p[0].size == 72 and set(np.diff(m2.hanging_p[1])) == {2, 4}
+    m3 = _stokes_adaptive_mesh(5)
+    assert (m3.n_cells, m3.n_dofs_v, m3.n_dofs_p, m3.n_levels_of_mesh) == (g[2]["cells"], g[2]["dofs_u"], g[2]["dofs_p"], g[2]["levels"])
+    for m in (m2, m3):
+        for hn, hp, hm, hw in (m.hanging_v, m.hanging_p):
+            assert np.allclose(np.add.reduceat(hw, hp[:-1]), 1.0, atol=1e-14)           # partition of unity
+            assert not np.isin(hm, hn).any()                                               # masters are not hanging
+        # a globally quadratic field satisfies the constraints exactly
+        f = lambda x: np.stack([x[:, 0] ** 2 + x[:, 1] * x[:, 2], x[:, 1] ** 2 - x[:, 0], x[:, 2] * x[:, 0]], axis=1)
+        assert np.abs(m.interpolate_v(f) - f(m.node_coords_v()).reshape(-1)).max() < 1e-14
+
+
+@pytest.mark.parametrize("n_second", [0, 5])
+def test_hanging_node_operators_equal_the_uniformly_refined_mesh(n_second):
+    """Operators with hanging-node constraints resolved (MatrixFree's read_dof_values / distribute_local_to_global;
+    oracle/oracle.cpp vmult_hanging): for a field of the adaptive space -- a quadratic velocity, a linear pressure --
+    and a constant viscosity, the bilinear forms a(u, u), (p, div u), (p, p) on the adaptive mesh equal those on the
+    uniformly refined mesh that contains it (Gauss-3 is exact for both), the operator is symmetric, and the
+    sum-factorised and the dense cell formulation agree."""
+    from aspect_amd import adaptivemesh as am
+    m = _stokes_adaptive_mesh(n_second)
+    m.cmask_v[:] = 0                                     # no boundary constraints: the forms are the plain integrals
+    pa = am.AdaptiveProblem(m, lambda x: np.full(x.shape[0], 2.5), per_q=True, pressure_scaling=0.75)
+    pu = cases.convection_box(3, m.max_level)
+    pu.bc = [bm.BC_NONE] * 6
+    pu.eta = lambda x: np.full(x.shape[0], 2.5)
+    pu.pressure_scaling = 0.75
+    pu.build_single_level()
+    sa, su = pyoracle.solver(pa, single_level=True), pyoracle.solver(pu, single_level=True)
+    fu = lambda x: np.stack([x[:, 0] ** 2 + x[:, 1] * x[:, 2], x[:, 1] ** 2 - 2 * x[:, 0] * x[:, 2], x[:, 2] * x[:, 0] + x[:, 1]], axis=1)
+    fp = lambda x: 1.0 + x[:, 0] - 2.0 * x[:, 1] + 0.5 * x[:, 2]
+    fin = pu.hier.finest
+    xa = np.concatenate([m.interpolate_v(fu), fp(m.node_coords_p())])       # (a linear pressure satisfies the Q1 constraints)
+    xu = np.concatenate([fu(fin.node_coords_v()).reshape(-1), fp(fin.node_coords_p())])
+    free = np.concatenate([~m.hanging_dofs_v(), ~np.isin(np.arange(m.n_nodes_p), m.hanging_p[0])])
+    nu_a, nu_u = m.n_dofs_v, fin.n_dofs_v
+    for which, sl_a, sl_u in ((capi.OP_A, slice(0, nu_a), slice(0, nu_u)), (capi.OP_MASS, slice(nu_a, None), slice(nu_u, None)),
+                              (capi.OP_STOKES, slice(None), slice(None))):
+        ya, yu = sa.vmult(which, xa[sl_a]), su.vmult(which, xu[sl_u])
+        ea, eu = (xa[sl_a] * ya)[free[sl_a]].sum(), (xu[sl_u] * yu).sum()
+        assert abs(ea - eu) <= 1e-12 * abs(eu), (which, ea, eu)
+        yd = sa.vmult(which, xa[sl_a], dense=True)
+        assert np.linalg.norm(ya - yd) <= 1e-12 * np.linalg.norm(yd)
+    rng = np.random.Generator(np.random.PCG64(11))
+    x, y = rng.uniform(-1, 1, nu_a), rng.uniform(-1, 1, nu_a)
+    assert abs(x @ sa.vmult(capi.OP_A, y) - y @ sa.vmult(capi.OP_A, x)) <= 1e-12 * abs(x @ sa.vmult(capi.OP_A, y))
+    # hanging rows are identity rows; B^T leaves the pressure rows alone
+    z = rng.uniform(-1, 1, nu_a + m.n_dofs_p)
+    yb = sa.vmult(capi.OP_BT, z)
+    hv = m.hanging_dofs_v()
+    assert np.array_equal(sa.vmult(capi.OP_A, x)[hv], x[hv]) and np.array_equal(yb[:nu_a][hv], z[:nu_a][hv])
+    sa.close()
+    su.close()
