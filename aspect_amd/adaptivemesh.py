@@ -14,8 +14,11 @@ then locally, as one level for `agmg_level_desc`:
   1/4, 1/2, 3/4;
 * constraint masks, cell extents and quadrature-point coordinates as `boxmesh.Level` has them.
 
-Multigrid levels of such a mesh (local smoothing: refinement-edge masks, interface operators, transfers between
-partially refined levels) are NOT built: a level of this class is used on its own (`capi.Solver(..., single_level=True)`).
+`AdaptiveMGHierarchy` adds the multigrid levels of local smoothing (stokes_matrix_free_local_smoothing.cc:1760-1877):
+level l holds ALL cells of refinement level l (active or refined), numbered without hanging nodes; its refinement-edge
+mask marks the nodes on faces whose neighbour of the same level does not exist (MGTools::extract_inner_interface_dofs);
+its copy table pairs the nodes of the cells that are active on the level with the active-mesh nodes, refinement-edge
+nodes left out (MGLevelGlobalTransfer::fill_copy_indices); parents and child numbers drive the transfers.
 """
 from __future__ import annotations
 
@@ -229,6 +232,184 @@ class AdaptiveBoxLevel:
         return u.reshape(-1)
 
 
+    def nodal_to_qpoints(self, nodal):
+        """Q2 field at the velocity nodes (hanging nodes holding their constrained values) -> [n_cells][nq]."""
+        return nodal[self.cell_nodes_v.astype(np.int64)] @ bm.tensor_shape([bm.N2] * self.dim).T
+
+    def condense(self, vec_nodes, hanging):
+        """AffineConstraints::condense of a right-hand side [n_nodes][ncomp]: rows of hanging nodes go to their masters."""
+        hn, hp, hm, hw = hanging
+        for i, h in enumerate(hn):
+            k = slice(hp[i], hp[i + 1])
+            np.add.at(vec_nodes, hm[k].astype(np.int64), hw[k, None] * vec_nodes[h][None, :])
+            vec_nodes[h] = 0.0
+        return vec_nodes
+
+    def assemble_rhs_u(self, force_func=None, force_q=None):
+        """int rho g . phi_u over the active cells (Gauss-3), hanging rows condensed, constrained rows zeroed."""
+        dim = self.dim
+        f = force_q(self) if force_q is not None else force_func(self.qpoint_coords().reshape(-1, dim)).reshape(self.n_cells, -1, dim)
+        Nq = bm.tensor_shape([bm.N2] * dim)
+        W = bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * dim).reshape(-1)
+        loc = np.einsum("qi,q,c,cqd->cid", Nq, W, np.prod(self.cell_h, axis=1), f)
+        out = np.zeros((self.n_nodes_v, dim))
+        np.add.at(out, self.cell_nodes_v.astype(np.int64), loc)
+        out = self.condense(out, self.hanging_v).reshape(-1)
+        out[self.constrained_dofs_v()] = 0.0
+        return out
+
+    def distribute_v(self, u):
+        """AffineConstraints::distribute on a velocity vector: hanging nodes take their constrained values."""
+        u = np.array(u, dtype=np.float64).reshape(self.n_nodes_v, self.dim)
+        hn, hp, hm, hw = self.hanging_v
+        for i, h in enumerate(hn):
+            u[h] = (hw[hp[i]:hp[i + 1], None] * u[hm[hp[i]:hp[i + 1]].astype(np.int64)]).sum(axis=0)
+        return u.reshape(-1)
+
+
+class AdaptiveMGLevel:
+    """All cells of refinement level `l` of an adaptively refined box (one level of local smoothing)."""
+
+    def __init__(self, active, l, cells, parent_cell, child_index):
+        dim = self.dim = active.dim
+        self.level = l
+        self.general = False
+        self.periodic = [False] * dim
+        self.cell_ijk = np.asarray(cells, dtype=np.int64).reshape(-1, dim)
+        self.n_cells = self.cell_ijk.shape[0]
+        self.parent_cell = None if parent_cell is None else np.asarray(parent_cell, dtype=np.int32)
+        self.child_index = None if child_index is None else np.asarray(child_index, dtype=np.uint8)
+        ncd = active.reps * (1 << l)
+        self.h = active.extents / ncd
+        self.cell_h = np.repeat(self.h[None, :], self.n_cells, axis=0)
+        lat_n = 2 * ncd + 1
+        mul = np.concatenate([[1], np.cumprod(lat_n[:-1])]).astype(np.int64)
+        loc3 = np.indices((3,) * dim).reshape(dim, -1)[::-1].T
+        loc2 = np.indices((2,) * dim).reshape(dim, -1)[::-1].T
+
+        def number(X):
+            key = X.reshape(-1, dim) @ mul
+            uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+            order = np.argsort(first, kind="stable")
+            new_of = np.empty(uniq.size, dtype=np.int64)
+            new_of[order] = np.arange(uniq.size)
+            return new_of[inv].reshape(X.shape[:2]).astype(np.uint32), X.reshape(-1, dim)[first[order]]
+        self.cell_nodes_v, self.lattice_v = number(2 * self.cell_ijk[:, None, :] + loc3[None, :, :])
+        self.cell_nodes_p, self.lattice_p = number(2 * self.cell_ijk[:, None, :] + 2 * loc2[None, :, :])
+        self.n_nodes_v, self.n_nodes_p = self.lattice_v.shape[0], self.lattice_p.shape[0]
+        mask = np.zeros(self.n_nodes_v, dtype=np.uint8)
+        allbits = (1 << dim) - 1
+        for d in range(dim):
+            for side in range(2):
+                code = active.bc[2 * d + side]
+                on = self.lattice_v[:, d] == (0 if side == 0 else lat_n[d] - 1)
+                if code == bm.BC_ZERO:
+                    mask[on] |= allbits
+                elif code == bm.BC_TANGENTIAL:
+                    mask[on] |= (1 << d)
+                elif code >= bm.BC_COMPONENTS:
+                    mask[on] |= (code - bm.BC_COMPONENTS) & allbits
+        self.cmask_v = mask
+        self.cmask_p = np.zeros(self.n_nodes_p, dtype=np.uint8)
+        # refinement edge: faces of a cell whose neighbour on this level does not exist (and is not the domain boundary)
+        here = {tuple(int(v) for v in c) for c in self.cell_ijk}
+        self.edge_v = np.zeros(self.n_nodes_v, dtype=np.uint8)
+        self.edge_p = np.zeros(self.n_nodes_p, dtype=np.uint8)
+        for n, c in enumerate(self.cell_ijk):
+            for d in range(dim):
+                for side in range(2):
+                    q = c.copy()
+                    q[d] += 1 if side else -1
+                    if q[d] < 0 or q[d] >= ncd[d] or tuple(int(v) for v in q) in here:
+                        continue
+                    self.edge_v[self.cell_nodes_v[n][loc3[:, d] == 2 * side]] = 1
+                    self.edge_p[self.cell_nodes_p[n][loc2[:, d] == side]] = 1
+        self.index_of = {tuple(int(v) for v in c): n for n, c in enumerate(self.cell_ijk)}
+
+    @property
+    def n_dofs_v(self):
+        return self.dim * self.n_nodes_v
+
+    @property
+    def n_dofs_p(self):
+        return self.n_nodes_p
+
+    def qpoint_coords(self):
+        q = np.indices((3,) * self.dim).reshape(self.dim, -1)[::-1]
+        out = np.zeros((self.n_cells, 3 ** self.dim, self.dim))
+        for d in range(self.dim):
+            out[:, :, d] = (self.cell_ijk[:, d:d + 1] + bm.GAUSS3_X[q[d]][None, :]) * self.h[d]
+        return out
+
+    def constrained_dofs_v(self):
+        bits = (self.cmask_v[:, None] >> np.arange(self.dim)[None, :]) & 1
+        return bits.reshape(-1).astype(bool)
+
+
+class AdaptiveMGHierarchy:
+    """Levels 0..max_level of local smoothing under an AdaptiveBoxLevel (`active`); `finest` is the ACTIVE mesh (the
+    vectors of the solver live there), `levels` the multigrid levels."""
+
+    def __init__(self, active):
+        self.dim = dim = active.dim
+        self.active = active
+        leaves = {c: n for n, c in enumerate(active.leaves)}
+        coarse = bm.Level(dim, active.extents, active.reps, 0, active.bc)
+        cells = [tuple(int(v) for v in c) for c in coarse.cell_ijk]
+        parent, child = None, None
+        self.levels = []
+        for l in range(active.max_level + 1):
+            lev = AdaptiveMGLevel(active, l, cells, parent, child)
+            lev.active_cell = np.array([leaves.get((l,) + c, -1) for c in cells], dtype=np.int64)
+            self.levels.append(lev)
+            nxt, parent, child = [], [], []
+            for n, c in enumerate(cells):
+                if lev.active_cell[n] >= 0:
+                    continue
+                for ch in range(1 << dim):
+                    nxt.append(tuple(2 * c[d] + ((ch >> d) & 1) for d in range(dim)))
+                    parent.append(n)
+                    child.append(ch)
+            cells = nxt
+        assert not cells and sum(int((lv.active_cell >= 0).sum()) for lv in self.levels) == active.n_cells
+        for lev in self.levels:                      # copy tables: (active node, level node) of the cells active on the level
+            act = np.flatnonzero(lev.active_cell >= 0)
+            for name, cn_a, cn_l, edge in (("v", active.cell_nodes_v, lev.cell_nodes_v, lev.edge_v),
+                                           ("p", active.cell_nodes_p, lev.cell_nodes_p, lev.edge_p)):
+                a = cn_a[lev.active_cell[act]].reshape(-1).astype(np.int64)
+                b = cn_l[act].reshape(-1).astype(np.int64)
+                keep = edge[b] == 0
+                pairs = np.unique(np.stack([a[keep], b[keep]], axis=1), axis=0) if keep.any() else np.zeros((0, 2), dtype=np.int64)
+                assert np.unique(pairs[:, 1]).size == pairs.shape[0] and np.unique(pairs[:, 0]).size == pairs.shape[0]
+                setattr(lev, "copy_active_" + name, pairs[:, 0].astype(np.uint32))
+                setattr(lev, "copy_level_" + name, pairs[:, 1].astype(np.uint32))
+
+    @property
+    def finest(self):
+        return self.active
+
+    @property
+    def n_levels(self):
+        return len(self.levels)
+
+    def level_tables(self, active_table, restrict):
+        """Coefficient tables of the levels from the table of the active cells: a cell that is active on its level keeps
+        its row, a refined cell takes `restrict(rows of its 2^dim children [parents][children][k])` (the DG transfer of
+        the reference, MGTransferMF::interpolate_to_mg, local_smoothing.cc:388-445)."""
+        out = [None] * self.n_levels
+        for l in range(self.n_levels - 1, -1, -1):
+            lev = self.levels[l]
+            t = np.zeros((lev.n_cells, active_table.shape[1]))
+            act = lev.active_cell >= 0
+            t[act] = active_table[lev.active_cell[act]]
+            if l + 1 < self.n_levels and self.levels[l + 1].n_cells:
+                nxt = self.levels[l + 1]
+                kids = out[l + 1].reshape(-1, 1 << self.dim, active_table.shape[1])
+                t[nxt.parent_cell[::1 << self.dim]] = restrict(kids)
+            out[l] = t
+        return out
+
+
 class AdaptiveHierarchy:
     """One-level 'hierarchy' around an AdaptiveBoxLevel (what capi.Solver(single_level=True) walks)."""
 
@@ -248,15 +429,31 @@ class AdaptiveHierarchy:
 class AdaptiveProblem:
     """The minimum capi.Solver needs: the level and its viscosity table (cell-constant or per quadrature point)."""
 
-    def __init__(self, level, eta, per_q=True, pressure_scaling=1.0, is_compressible=False):
-        self.hier = AdaptiveHierarchy(level)
+    def __init__(self, level, eta, per_q=True, pressure_scaling=1.0, is_compressible=False, multigrid=False,
+                 force=None, force_q=None, initial_pressure=None, tol=1e-7, n_cheap=200, n_expensive=0):
+        """multigrid: also the levels of local smoothing (AdaptiveMGHierarchy; level tables: cell-constant
+        viscosities, child means on refined cells) and the right-hand side of `force` / `force_q`."""
+        self.hier = AdaptiveMGHierarchy(level) if multigrid else AdaptiveHierarchy(level)
         self.dim = level.dim
         self.name = "adaptive_box"
-        self.tol, self.restart, self.n_cheap, self.n_expensive, self.krylov, self.idr_s = 1e-7, 100, 200, 0, "gmres", 2
+        self.tol, self.restart, self.n_cheap, self.n_expensive, self.krylov, self.idr_s = tol, 100, n_cheap, n_expensive, "gmres", 2
         self.pressure_scaling = pressure_scaling
         self.is_compressible = is_compressible
         eq = eta(level.qpoint_coords().reshape(-1, level.dim)).reshape(level.n_cells, -1)
         self.eta_active = eq if per_q else (eq.shape[1] / np.sum(1.0 / eq, axis=1))[:, None]
-        self.eta_levels = [self.eta_active]
         self.eta_min, self.eta_max = float(self.eta_active.min()), float(self.eta_active.max())
         self.free_surface = None
+        if not multigrid:
+            self.eta_levels = [self.eta_active]
+            return
+        if per_q:       # (levels carry cell-constant tables: the mean over the q-points, then child means)
+            cellv = (eq @ bm.tensor_shape([bm.GAUSS3_W.reshape(3, 1)] * level.dim).reshape(-1))[:, None]
+        else:
+            cellv = self.eta_active
+        self.eta_levels = self.hier.level_tables(cellv, lambda kids: kids.mean(axis=1))
+        self.rhs_u = level.assemble_rhs_u(force, force_q) if (force is not None or force_q is not None) else np.zeros(level.n_dofs_v)
+        self.rhs_p = np.zeros(level.n_dofs_p)
+        self.p0 = np.zeros(level.n_dofs_p) if initial_pressure is None else initial_pressure(level.node_coords_p()) / pressure_scaling
+        self.p0[level.hanging_p[0].astype(np.int64)] = 0.0       # (constrained entries of the start vector are zero)
+        self.u0 = None
+        self.dilation = None

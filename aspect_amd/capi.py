@@ -58,6 +58,8 @@ class LevelDesc(C.Structure):
         ("hanging_nodes_v", c_u32p), ("hanging_ptr_v", c_i32p), ("hanging_master_v", c_u32p), ("hanging_weight_v", c_dp),
         ("hanging_nodes_p", c_u32p), ("hanging_ptr_p", c_i32p), ("hanging_master_p", c_u32p), ("hanging_weight_p", c_dp),
         ("refinement_edge_v", c_u8p), ("refinement_edge_p", c_u8p),
+        ("n_copy_v", C.c_int32), ("n_copy_p", C.c_int32),
+        ("copy_active_v", c_u32p), ("copy_level_v", c_u32p), ("copy_active_p", c_u32p), ("copy_level_p", c_u32p),
     ]
 
 
@@ -232,7 +234,10 @@ class Solver:
                 self._check(lib.set_communicator(self.ctx, C.addressof(transport.struct)))
         for l, lev in enumerate(hier.levels):
             self._set_level(l, lev)
-        self._check(lib.set_level(self.ctx, ACTIVE, None))
+        if getattr(hier, "active", None) is not None:       # adaptive refinement: the active mesh has tables of its own
+            self._set_level(ACTIVE, hier.active)
+        else:
+            self._check(lib.set_level(self.ctx, ACTIVE, None))
         comp = int(bool(getattr(problem, "is_compressible", False)))   # material_model.is_compressible()
         for l, lev in enumerate(hier.levels):
             self._set_coeff(l, problem.eta_levels[l], is_compressible=comp)
@@ -297,7 +302,24 @@ class Solver:
                 setattr(d, "hanging_master_" + name, _ptr(arrs[2], C.c_uint32))
                 setattr(d, "hanging_weight_" + name, _ptr(arrs[3], C.c_double))
                 keep += arrs
-        if l > 0 and lev.level > 0:
+        if getattr(lev, "edge_v", None) is not None:       # a level of local smoothing under an adaptive mesh
+            arrs = [np.ascontiguousarray(lev.edge_v, dtype=np.uint8), np.ascontiguousarray(lev.edge_p, dtype=np.uint8)]
+            d.refinement_edge_v, d.refinement_edge_p = _ptr(arrs[0], C.c_uint8), _ptr(arrs[1], C.c_uint8)
+            for name in ("v", "p"):
+                ca = np.ascontiguousarray(getattr(lev, "copy_active_" + name), dtype=np.uint32)
+                cl = np.ascontiguousarray(getattr(lev, "copy_level_" + name), dtype=np.uint32)
+                setattr(d, "n_copy_" + name, ca.size)
+                setattr(d, "copy_active_" + name, _ptr(ca, C.c_uint32))
+                setattr(d, "copy_level_" + name, _ptr(cl, C.c_uint32))
+                arrs += [ca, cl]
+            keep += arrs
+        if getattr(lev, "parent_cell", None) is not None:
+            par = np.ascontiguousarray(lev.parent_cell, dtype=np.int32)
+            chi = np.ascontiguousarray(lev.child_index, dtype=np.uint8)
+            d.parent_cell = _ptr(par, C.c_int32)
+            d.child_index = _ptr(chi, C.c_uint8)
+            keep += [par, chi]
+        elif l > 0 and lev.level > 0 and not hasattr(lev, "edge_v"):
             nch = 1 << lev.dim
             par = (np.arange(lev.n_cells, dtype=np.int32) // nch).astype(np.int32)
             chi = (np.arange(lev.n_cells, dtype=np.int32) % nch).astype(np.uint8)

@@ -164,6 +164,16 @@ typedef struct agmg_level_desc {
   const uint32_t *hanging_nodes_p; const int32_t *hanging_ptr_p; const uint32_t *hanging_master_p; const double *hanging_weight_p;
   const uint8_t *refinement_edge_v;  /* [n_nodes_v] 1: node on the refinement edge of this level, or NULL */
   const uint8_t *refinement_edge_p;  /* [n_nodes_p] or NULL */
+  /* Local smoothing on an adaptively refined mesh (the active mesh is then set with a descriptor of
+   * its own, agmg_set_level(AGMG_ACTIVE, desc), and level l holds ALL cells of refinement level l):
+   * MGLevelGlobalTransfer::copy_indices of the level: node copy_level_x[i] of this level is node
+   * copy_active_x[i] of the active mesh (the nodes of the cells that are active on the level, its
+   * refinement-edge nodes left out).  copy_to_mg fills the level defects through them, copy_from_mg
+   * gathers the level solutions (local_smoothing.cc:1040-1058, PreconditionMG::vmult).  n_copy_x == 0
+   * on every level: uniformly refined mesh, the active mesh is the finest level. */
+  int32_t n_copy_v, n_copy_p;
+  const uint32_t *copy_active_v; const uint32_t *copy_level_v;
+  const uint32_t *copy_active_p; const uint32_t *copy_level_p;
 } agmg_level_desc;
 
 /* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */

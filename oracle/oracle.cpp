@@ -146,11 +146,18 @@ struct Level {
   std::vector<int32_t> hang_ptr[2];
   Vec hang_w[2];
   bool has_hanging() const { return !hang_n[0].empty() || !hang_n[1].empty(); }
+  // local smoothing on adaptive meshes: cmv / cmp above hold boundary + refinement-edge rows (the level operator of
+  // MatrixFreeOperators::Base: identity on both), bnd_v / bnd_p the boundary rows alone (transfers, interface operators)
+  std::vector<uint8_t> bnd_v, bnd_p, edge_v, edge_p;
+  bool has_edge = false;
+  std::vector<uint32_t> copy_act[2], copy_lev[2];   // MGLevelGlobalTransfer::copy_indices, [0] velocity, [1] pressure nodes
   bool set = false;
   int ndv() const { return dim * n_nodes_v; }
   int ndp() const { return n_nodes_p; }
   bool constrained_v(int node, int c) const { return (cmv[node] >> c) & 1; }
   bool constrained_p(int node) const { return cmp[node] & 1; }
+  bool boundary_v(int node, int c) const { return ((has_edge ? bnd_v[node] : cmv[node]) >> c) & 1; }
+  bool boundary_p(int node) const { return (has_edge ? bnd_p[node] : cmp[node]) & 1; }
 };
 
 struct Geo {  // geometry at one q-point
@@ -997,8 +1004,14 @@ struct Ctx {
   std::vector<Chebyshev> chebA, chebS;
   bool smoothers_ready = false;
   int nA_cheap = 0, nA_exp = 0, nS_cheap = 0, nS_exp = 0;
+  Level active;                // the active mesh when it is not the finest level (adaptive refinement)
+  bool has_active = false;
   Level &fin() { return levels.back(); }
+  Level &act() { return has_active ? active : levels.back(); }
+  const Level &act() const { return has_active ? active : levels.back(); }
 };
+
+void active_vmult(Ctx &C, int which, double *dst, const double *src);   // operators of the active mesh, hanging nodes resolved
 
 template <int DIM>
 void level_A(const Level &L, Vec &d, const Vec &s) { op_vmult<DIM>(L, L.cd, M_A, s.data(), nullptr, d.data(), nullptr); }
@@ -1040,15 +1053,18 @@ void transfer(const Ctx &C, int which, int fine_level, bool prolong, Vec &dst, c
     }
   };
   std::vector<uint32_t> pn;
+  // (local smoothing on adaptive meshes: a coarse cell that is active on its level has no children and takes no part)
   for (int p = 0; p < Cs.n_cells; ++p) {
+    if (children[p][0] < 0) continue;
     patch_nodes(p, pn);
     for (int i = 0; i < npatch; ++i) weight[pn[i]] += 1.0;
   }
-  for (auto &w : weight) w = 1.0 / w;
-  auto coarse_constrained = [&](int node, int c) { return vel ? Cs.constrained_v(node, c) : Cs.constrained_p(node); };
+  for (auto &w : weight) w = w > 0.0 ? 1.0 / w : 0.0;
+  auto coarse_constrained = [&](int node, int c) { return vel ? Cs.boundary_v(node, c) : Cs.boundary_p(node); };
   int n[3] = {n1, n1, DIM == 3 ? n1 : 1};
   std::vector<double> a(125), b(125), loc(27);
   for (int p = 0; p < Cs.n_cells; ++p) {
+    if (children[p][0] < 0) continue;
     patch_nodes(p, pn);
     for (int c = 0; c < ncomp; ++c) {
       if (prolong) {
@@ -1100,23 +1116,69 @@ struct MG {
   void smoother_smooth(int l, Vec &u, const Vec &rhs) {  // ::smooth
     for (int i = 0; i < steps(); ++i) cheb(l).step(u, rhs);
   }
+  // MGInterfaceOperator on a level with a refinement edge (MatrixFreeOperators::Base::vmult_interface_down / _up):
+  // the operator with the boundary rows alone constrained, applied to the source without (down) or with only (up) its
+  // refinement-edge entries, of which the edge rows (down) or all other rows (up) are kept
+  void interface(int l, bool down, Vec &d, const Vec &s) {
+    Level &L = C.levels[l];
+    const bool vel = which == AGMG_OP_A;
+    const int nc = vel ? DIM : 1;
+    const std::vector<uint8_t> &edge = vel ? L.edge_v : L.edge_p;
+    Vec x(s);
+    for (size_t i = 0; i < x.size(); ++i) if ((edge[i / nc] != 0) == down) x[i] = 0.0;
+    std::swap(L.cmv, L.bnd_v); std::swap(L.cmp, L.bnd_p);
+    matvec(l, d, x);
+    std::swap(L.cmv, L.bnd_v); std::swap(L.cmp, L.bnd_p);
+    for (size_t i = 0; i < d.size(); ++i) if ((edge[i / nc] != 0) != down) d[i] = 0.0;
+    // (rows of boundary nodes: matvec returned the identity there; the reference's apply_add writes nothing)
+    for (size_t i = 0; i < d.size(); ++i) if (vel ? L.boundary_v(int(i / nc), int(i % nc)) : L.boundary_p(int(i))) d[i] = 0.0;
+  }
+  // Multigrid::level_v_step with set_edge_matrices(interface, interface) (local_smoothing.cc:1045, 1053)
   void level_v_step(int l) {
     if (l == 0) { smoother_apply(0, solution[0], defect[0]); return; }
+    const bool edge = C.levels[l].has_edge;
     smoother_apply(l, solution[l], defect[l]);
     matvec(l, t[l], solution[l]);
+    if (edge) {                                  // edge_out->vmult_add
+      Vec e(t[l].size());
+      interface(l, true, e, solution[l]);
+      axpy(t[l], 1.0, e);
+    }
     for (size_t i = 0; i < t[l].size(); ++i) t[l][i] = defect[l][i] - t[l][i];
     transfer<DIM>(C, which, l, false, defect[l - 1], t[l]);
     level_v_step(l - 1);
     transfer<DIM>(C, which, l, true, solution[l], solution[l - 1]);
+    if (edge) {                                  // edge_in->Tvmult: defect -= (interface up) solution
+      Vec e(t[l].size());
+      interface(l, false, e, solution[l]);
+      axpy(defect[l], -1.0, e);
+    }
     smoother_smooth(l, solution[l], defect[l]);
   }
   void vcycle(Vec &dst, const Vec &src) {   // PreconditionMG::vmult
     const int nl = int(C.levels.size());
     defect.resize(nl); solution.resize(nl); t.resize(nl);
     for (int l = 0; l < nl; ++l) { defect[l].assign(size(l), 0.0); solution[l].assign(size(l), 0.0); t[l].assign(size(l), 0.0); }
-    defect[nl - 1] = src;
+    if (!C.has_active) {
+      defect[nl - 1] = src;
+      level_v_step(nl - 1);
+      dst = solution[nl - 1];
+      return;
+    }
+    // copy_to_mg / copy_from_mg through the copy indices of every level (MGLevelGlobalTransfer)
+    const int sp = which == AGMG_OP_A ? 0 : 1, nc = which == AGMG_OP_A ? DIM : 1;
+    for (int l = 0; l < nl; ++l) {
+      const Level &L = C.levels[l];
+      for (size_t i = 0; i < L.copy_act[sp].size(); ++i)
+        for (int c = 0; c < nc; ++c) defect[l][size_t(L.copy_lev[sp][i]) * nc + c] = src[size_t(L.copy_act[sp][i]) * nc + c];
+    }
     level_v_step(nl - 1);
-    dst = solution[nl - 1];
+    dst.assign(src.size(), 0.0);
+    for (int l = 0; l < nl; ++l) {
+      const Level &L = C.levels[l];
+      for (size_t i = 0; i < L.copy_act[sp].size(); ++i)
+        for (int c = 0; c < nc; ++c) dst[size_t(L.copy_act[sp][i]) * nc + c] = solution[l][size_t(L.copy_lev[sp][i]) * nc + c];
+    }
   }
 };
 
@@ -1152,14 +1214,14 @@ struct BlockPrec {
   BlockPrec(Ctx &c, bool e) : C(c), expensive(e), mgA(c, AGMG_OP_A), mgS(c, AGMG_OP_MASS) {}
   // BlockSchurGMGPreconditioner::vmult (stokes_matrix_free.h:237-354)
   void vmult(Vec &dst, const Vec &src) {
-    Level &L = C.fin();
+    Level &L = C.act();
     const int nu = L.ndv(), np = L.ndp();
     Vec sp(src.begin() + nu, src.end()), su(src.begin(), src.begin() + nu);
     Vec dp(np, 0.0), du(nu, 0.0);
     if (expensive) {
       const double nrm = norm(sp);
       if (nrm > 1e-50) {
-        LinOp A = [&](Vec &d, const Vec &s) { mass_vmult<DIM>(L, C.active_cd, s.data(), d.data()); };
+        LinOp A = [&](Vec &d, const Vec &s) { active_vmult(C, AGMG_OP_MASS, d.data(), s.data()); };
         LinOp P = [&](Vec &d, const Vec &s) { mgS.vcycle(d, s); };
         CGResult r = solver_cg(A, P, dp, sp, 100, nrm * C.opt.S_block_tolerance, false, false);
         nS += r.its;
@@ -1168,12 +1230,16 @@ struct BlockPrec {
     } else { mgS.vcycle(dp, sp); nS += 1; }
     for (auto &v : dp) v *= -1.0;
     // utmp = src_u - B^T dst_p
-    Vec utmp(nu), zero_u(nu, 0.0), dummy_p(np);
-    op_vmult<DIM>(L, C.active_cd, M_BT, zero_u.data(), dp.data(), utmp.data(), dummy_p.data());
-    for (int i = 0; i < nu; ++i) utmp[i] = su[i] - utmp[i];
+    Vec utmp(nu);
+    {
+      Vec xin(nu + np, 0.0), yout(nu + np);
+      std::copy(dp.begin(), dp.end(), xin.begin() + nu);
+      active_vmult(C, AGMG_OP_BT, yout.data(), xin.data());
+      for (int i = 0; i < nu; ++i) utmp[i] = su[i] - yout[i];
+    }
     if (expensive) {
       const double nrm = norm(utmp);
-      LinOp A = [&](Vec &d, const Vec &s) { op_vmult<DIM>(L, C.active_cd, M_A, s.data(), nullptr, d.data(), nullptr); };
+      LinOp A = [&](Vec &d, const Vec &s) { active_vmult(C, AGMG_OP_A, d.data(), s.data()); };
       LinOp P = [&](Vec &d, const Vec &s) { mgA.vcycle(d, s); };
       CGResult r = C.opt.A_block_is_symmetric ? solver_cg(A, P, du, utmp, 1000, nrm * C.opt.A_block_tolerance, false, false)
                                               : solver_bicgstab(A, P, du, utmp, 1000, nrm * C.opt.A_block_tolerance);
@@ -1390,16 +1456,20 @@ int solver_idr(const LinOp &A, const LinOp &P, Vec &x, const Vec &b, int s, Cont
 // ------------------------------------------------------------------ solve
 template <int DIM>
 int do_solve(Ctx &C, const double *rhs_in, double *x_io, int newton, agmg_solve_report *rep) {
-  Level &L = C.fin();
+  Level &L = C.act();
   const int nu = L.ndv(), np = L.ndp(), n = nu + np;
   if (!C.smoothers_ready) setup_smoothers<DIM>(C);
   Vec rhs(rhs_in, rhs_in + n), x(x_io, x_io + n);
   // current_constraints.set_zero(initial guess), local_smoothing.cc:1116
   for (int nd = 0; nd < L.n_nodes_v; ++nd)
     for (int c = 0; c < DIM; ++c) if (L.constrained_v(nd, c)) x[size_t(nd) * DIM + c] = 0.0;
+  // (hanging-node entries: zero in the start vector like every constrained entry, identity rows in the operator)
+  for (int sp = 0; sp < 2; ++sp)
+    for (uint32_t h : L.hang_n[sp])
+      for (int c = 0; c < (sp == 0 ? DIM : 1); ++c) x[sp == 0 ? size_t(h) * DIM + c : size_t(nu) + h] = 0.0;
   LinOp A = [&](Vec &d, const Vec &s) {
     d.resize(n);
-    op_vmult<DIM>(L, C.active_cd, M_STOKES, s.data(), s.data() + nu, d.data(), d.data() + nu);
+    active_vmult(C, AGMG_OP_STOKES, d.data(), s.data());
   };
   double tol;
   Vec tmp(n);
@@ -1450,6 +1520,17 @@ int do_solve(Ctx &C, const double *rhs_in, double *x_io, int newton, agmg_solve_
   rep->n_history = 0;
   for (double v : cc.history) if (rep->n_history < 2048) rep->history[rep->n_history++] = v;
   for (double v : ce.history) if (rep->n_history < 2048) rep->history[rep->n_history++] = v;
+  // current_constraints.distribute(solution): hanging nodes take the values of their constraints
+  for (int sp = 0; sp < 2; ++sp) {
+    const int nc = sp == 0 ? DIM : 1;
+    const size_t off = sp == 0 ? 0 : nu;
+    for (size_t i = 0; i < L.hang_n[sp].size(); ++i)
+      for (int c = 0; c < nc; ++c) {
+        double v = 0;
+        for (int k = L.hang_ptr[sp][i]; k < L.hang_ptr[sp][i + 1]; ++k) v += L.hang_w[sp][k] * x[off + size_t(L.hang_m[sp][k]) * nc + c];
+        x[off + size_t(L.hang_n[sp][i]) * nc + c] = v;
+      }
+  }
   std::copy(x.begin(), x.end(), x_io);
   return status;
 }
@@ -1458,6 +1539,8 @@ int do_solve(Ctx &C, const double *rhs_in, double *x_io, int newton, agmg_solve_
 
 }  // namespace
 
+
+
 // ====================================================================== C API
 // correct_stokes_rhs (local_smoothing.cc:761-898): rhs += -M u0 with u0 read WITHOUT the constraints
 // (read_dof_values_plain, :813, 817), no Newton terms, no dilation LHS term (only the deviatoric part,
@@ -1465,7 +1548,7 @@ int do_solve(Ctx &C, const double *rhs_in, double *x_io, int newton, agmg_solve_
 // stabilisation likewise with plain reads (:853-888).
 template <int DIM>
 static void rhs_correction_impl(Ctx &C, const double *u0, double *rhs) {
-  const Level &L = C.fin();
+  const Level &L = C.act();
   CellData cd = C.active_cd.set ? C.active_cd : L.cd;
   cd.is_compressible = cd.is_compressible || cd.dilation;
   cd.newton = 0; cd.dilation = 0;
@@ -1546,12 +1629,10 @@ void oracle_destroy(oracle_ctx *o) { delete o; }
 
 int oracle_set_level(oracle_ctx *o, int level, const agmg_level_desc *d) {
   Ctx &C = o->c;
-  if (level == AGMG_ACTIVE) {
-    if (d) { g_error = "oracle: active mesh must alias the finest level (desc == NULL)"; return -1; }
-    return 0;
-  }
-  if (level < 0 || level >= int(C.levels.size())) { g_error = "bad level"; return -1; }
-  Level &L = C.levels[level];
+  if (level == AGMG_ACTIVE && !d) { C.has_active = false; return 0; }
+  if (level != AGMG_ACTIVE && (level < 0 || level >= int(C.levels.size()))) { g_error = "bad level"; return -1; }
+  if (level == AGMG_ACTIVE) { C.active = Level(); C.has_active = true; }
+  Level &L = level == AGMG_ACTIVE ? C.active : C.levels[level];
   const int dim = C.opt.dim;
   L.dim = dim; L.nv = ipow(3, dim); L.np = ipow(2, dim); L.nq = ipow(3, dim);
   L.n_cells = d->n_cells; L.n_nodes_v = d->n_nodes_v; L.n_nodes_p = d->n_nodes_p;
@@ -1577,13 +1658,39 @@ int oracle_set_level(oracle_ctx *o, int level, const agmg_level_desc *d) {
     const double *hw = sp == 0 ? d->hanging_weight_v : d->hanging_weight_p;
     L.hang_n[sp].clear(); L.hang_m[sp].clear(); L.hang_ptr[sp].clear(); L.hang_w[sp].clear();
     if (nh <= 0) continue;
-    if (C.levels.size() != 1) { g_error = "hanging-node constraints: one-level contexts only (first slice)"; return -2; }
+    if (level != AGMG_ACTIVE && C.levels.size() != 1) { g_error = "hanging-node constraints belong to the active mesh (multigrid levels have none)"; return -2; }
     if (!hn || !hp || !hm || !hw) { g_error = "incomplete hanging-node tables"; return -1; }
     L.hang_n[sp].assign(hn, hn + nh); L.hang_ptr[sp].assign(hp, hp + nh + 1);
     L.hang_m[sp].assign(hm, hm + hp[nh]); L.hang_w[sp].assign(hw, hw + hp[nh]);
     std::vector<uint8_t> is_h(nn, 0);
     for (uint32_t h : L.hang_n[sp]) { if (int(h) >= nn) { g_error = "hanging node out of range"; return -1; } is_h[h] = 1; }
     for (uint32_t m : L.hang_m[sp]) if (int(m) >= nn || is_h[m]) { g_error = "hanging-node master out of range or hanging itself"; return -1; }
+  }
+  // refinement edge + copy indices of a level of local smoothing
+  L.has_edge = false; L.bnd_v.clear(); L.bnd_p.clear(); L.edge_v.clear(); L.edge_p.clear();
+  if (level != AGMG_ACTIVE && (d->refinement_edge_v || d->refinement_edge_p)) {
+    if (!d->refinement_edge_v || !d->refinement_edge_p) { g_error = "refinement-edge masks come for both spaces"; return -1; }
+    L.edge_v.assign(d->refinement_edge_v, d->refinement_edge_v + L.n_nodes_v);
+    L.edge_p.assign(d->refinement_edge_p, d->refinement_edge_p + L.n_nodes_p);
+    bool any = false;
+    for (uint8_t e : L.edge_v) any |= e != 0;
+    for (uint8_t e : L.edge_p) any |= e != 0;
+    if (any) {
+      L.has_edge = true;
+      L.bnd_v = L.cmv; L.bnd_p = L.cmp;
+      const uint8_t all = uint8_t((1 << dim) - 1);
+      for (int i = 0; i < L.n_nodes_v; ++i) if (L.edge_v[i]) L.cmv[i] |= all;
+      for (int i = 0; i < L.n_nodes_p; ++i) if (L.edge_p[i]) L.cmp[i] |= 1;
+    }
+  }
+  for (int sp = 0; sp < 2; ++sp) {
+    const int nc = sp == 0 ? d->n_copy_v : d->n_copy_p, nn = sp == 0 ? L.n_nodes_v : L.n_nodes_p;
+    const uint32_t *ca = sp == 0 ? d->copy_active_v : d->copy_active_p, *cl = sp == 0 ? d->copy_level_v : d->copy_level_p;
+    L.copy_act[sp].clear(); L.copy_lev[sp].clear();
+    if (nc <= 0 || level == AGMG_ACTIVE) continue;
+    if (!ca || !cl) { g_error = "incomplete copy tables"; return -1; }
+    L.copy_act[sp].assign(ca, ca + nc); L.copy_lev[sp].assign(cl, cl + nc);
+    for (uint32_t v : L.copy_lev[sp]) if (int(v) >= nn) { g_error = "copy table: level node out of range"; return -1; }
   }
   for (size_t i = 0; i < L.cnv.size(); ++i) if (int(L.cnv[i]) >= L.n_nodes_v) { g_error = "cell_nodes_v out of range"; return -1; }
   for (size_t i = 0; i < L.cnp.size(); ++i) if (int(L.cnp[i]) >= L.n_nodes_p) { g_error = "cell_nodes_p out of range"; return -1; }
@@ -1596,7 +1703,7 @@ int oracle_set_coefficients(oracle_ctx *o, int level, const agmg_cell_data *d) {
   Ctx &C = o->c;
   CellData *cd;
   int nc;
-  if (level == AGMG_ACTIVE) { cd = &C.active_cd; nc = C.fin().n_cells; }
+  if (level == AGMG_ACTIVE) { cd = &C.active_cd; nc = C.act().n_cells; }
   else { cd = &C.levels[level].cd; nc = C.levels[level].n_cells; }
   cd->is_compressible = d->is_compressible; cd->newton = 0; cd->dilation = 0; cd->symmetrize = d->symmetrize_newton_system;
   cd->dil_lhs.clear(); cd->dil_de.clear(); cd->dil_dp.clear();
@@ -1636,9 +1743,9 @@ int oracle_set_free_surface_faces(oracle_ctx *o, const agmg_face_data *d) {
   if (!d || d->n_faces == 0) return 0;
   if (!d->face_cell || !d->face_number || !d->stabilization_term) { g_error = "free-surface face tables missing"; return -1; }
   if ((d->normal == nullptr) != (d->jxw == nullptr)) { g_error = "face normal and jxw come together"; return -1; }
-  if (!d->normal && C.fin().geom != AGMG_GEOM_CARTESIAN) { g_error = "general geometry needs face normals and JxW"; return -1; }
+  if (!d->normal && C.act().geom != AGMG_GEOM_CARTESIAN) { g_error = "general geometry needs face normals and JxW"; return -1; }
   for (int f = 0; f < d->n_faces; ++f)
-    if (int(d->face_cell[f]) >= C.fin().n_cells || d->face_number[f] >= 2 * dim) { g_error = "face table out of range"; return -1; }
+    if (int(d->face_cell[f]) >= C.act().n_cells || d->face_number[f] >= 2 * dim) { g_error = "face table out of range"; return -1; }
   cd.n_faces = d->n_faces;
   cd.face_cell.assign(d->face_cell, d->face_cell + d->n_faces);
   cd.face_no.assign(d->face_number, d->face_number + d->n_faces);
@@ -1663,7 +1770,7 @@ static void vmult_impl(Ctx &C, int which, int level, double *dst, const double *
 // identity rows): y = C^T A C x on the unconstrained DoFs.  Masters with a homogeneous Dirichlet bit contribute zero and
 // receive nothing (AffineConstraints merges the two kinds of constraints that way).
 static void vmult_hanging(Ctx &C, int which, int level, double *dst, const double *src, bool dense) {
-  Level &L = const_cast<Level &>(level == AGMG_ACTIVE ? C.fin() : C.levels[level]);
+  Level &L = const_cast<Level &>(level == AGMG_ACTIVE ? C.act() : C.levels[level]);
   const int dim = L.dim, nu = L.ndv(), np_ = L.ndp();
   const bool has_u = which != AGMG_OP_MASS, has_p = which != AGMG_OP_A;
   const size_t n = (has_u ? size_t(nu) : 0) + (has_p ? size_t(np_) : 0);     // A: u; mass: p; Stokes, B^T: [u; p]
@@ -1711,7 +1818,7 @@ static void vmult_hanging(Ctx &C, int which, int level, double *dst, const doubl
 }
 
 static void vmult_impl(Ctx &C, int which, int level, double *dst, const double *src, bool dense) {
-  const Level &L = level == AGMG_ACTIVE ? C.fin() : C.levels[level];
+  const Level &L = level == AGMG_ACTIVE ? C.act() : C.levels[level];
   const CellData &cd = level == AGMG_ACTIVE ? C.active_cd : L.cd;
   const int nu = L.ndv();
   if (L.has_hanging()) { vmult_hanging(C, which, level, dst, src, dense); return; }
@@ -1725,6 +1832,11 @@ static void vmult_impl(Ctx &C, int which, int level, double *dst, const double *
     else if (which == AGMG_OP_A) op_vmult<3>(L, cd, M_A, src, nullptr, dst, nullptr);
     else op_vmult<3>(L, cd, which == AGMG_OP_BT ? M_BT : M_STOKES, src, src + nu, dst, dst + nu);
   }
+}
+extern "C++" {
+namespace {
+void active_vmult(Ctx &C, int which, double *dst, const double *src) { vmult_impl(C, which, AGMG_ACTIVE, dst, src, false); }
+}
 }
 int oracle_rhs_correction(oracle_ctx *o, const double *u0, double *rhs) {
   if (o->c.opt.dim == 2) rhs_correction_impl<2>(o->c, u0, rhs); else rhs_correction_impl<3>(o->c, u0, rhs);
@@ -1745,7 +1857,7 @@ void cpu_simd_cells_v4(int, int, int, const int *, const uint32_t *, const uint3
 }
 int oracle_vmult_simd(oracle_ctx *o, int which, int level, double *dst, const double *src) {
   Ctx &C = o->c;
-  const Level &L = level == AGMG_ACTIVE ? C.fin() : C.levels[level];
+  const Level &L = level == AGMG_ACTIVE ? C.act() : C.levels[level];
   const CellData &cd = level == AGMG_ACTIVE ? C.active_cd : L.cd;
   if (C.opt.dim != 3 || L.geom != AGMG_GEOM_CARTESIAN || cd.newton || cd.dilation || cd.n_faces || which == AGMG_OP_MASS) return -1;
   const bool wide = __builtin_cpu_supports("avx512f");
@@ -1824,7 +1936,7 @@ int oracle_get_eigenvalue_estimates(oracle_ctx *o, int which, int level, double 
 
 int oracle_vcycle(oracle_ctx *o, int which, double *dst, const double *src) {
   Ctx &C = o->c;
-  const int n = which == AGMG_OP_A ? C.fin().ndv() : C.fin().ndp();
+  const int n = which == AGMG_OP_A ? C.act().ndv() : C.act().ndp();
   Vec d(n), s(src, src + n);
   if (C.opt.dim == 2) { if (!C.smoothers_ready) setup_smoothers<2>(C); MG<2> mg(C, which); mg.vcycle(d, s); }
   else { if (!C.smoothers_ready) setup_smoothers<3>(C); MG<3> mg(C, which); mg.vcycle(d, s); }
@@ -1834,7 +1946,7 @@ int oracle_vcycle(oracle_ctx *o, int which, double *dst, const double *src) {
 
 int oracle_precondition(oracle_ctx *o, int expensive, double *dst, const double *src) {
   Ctx &C = o->c;
-  const int n = C.fin().ndv() + C.fin().ndp();
+  const int n = C.act().ndv() + C.act().ndp();
   Vec d(n), s(src, src + n);
   if (C.opt.dim == 2) { if (!C.smoothers_ready) setup_smoothers<2>(C); BlockPrec<2> p(C, expensive != 0); p.vmult(d, s); }
   else { if (!C.smoothers_ready) setup_smoothers<3>(C); BlockPrec<3> p(C, expensive != 0); p.vmult(d, s); }
