@@ -151,6 +151,32 @@ struct agmg_ctx {
   std::vector<DeviceLevel> L;
   std::vector<HostLevel> H;
   bool has_hanging() const { for (const auto &h : H) if (h.has_hanging()) return true; return false; }
+  // ---- local smoothing on adaptively refined meshes: the active mesh has tables of its own (its
+  // hanging nodes are resolved around the device operators), every level carries its copy table, and a level with a
+  // refinement edge exists twice: L[l] with boundary + edge rows constrained (the level operator of
+  // MatrixFreeOperators::Base), ad.Lb[l] with the boundary rows alone (the interface operators)
+  struct Adaptive {
+    bool on = false;
+    DeviceLevel act;
+    HostLevel hact;                                     // (with the hanging-node CSRs of the active mesh)
+    std::vector<DeviceLevel> Lb;
+    std::vector<HostLevel> Hb;
+    std::vector<uint8_t *> edge[2], notedge[2];        // [velocity | pressure][level] device masks, nullptr without an edge
+    std::vector<std::vector<uint32_t>> copy_act[2], copy_lev[2];   // [velocity | pressure][level] MGLevelGlobalTransfer::copy_indices
+    // pull tables of level l - 1 that leave out the cells without children (restriction from level l), [space][l]
+    std::vector<uint32_t *> rpull_ptr[2], rpull_list[2];
+    double *xres = nullptr;      // a source vector with its hanging entries resolved [n_u + n_p]
+    size_t xres_cap = 0;
+    std::vector<double> hx, hy;  // host staging of the constraint handling and of the level copies
+  } ad;
+  bool has_edge(int l) const { return ad.on && l >= 0 && l < (int)ad.Lb.size() && ad.Lb[l].set; }
+  void free_adaptive_level(int l);
+  void free_adaptive_active();
+  // operators of the active mesh with the hanging nodes resolved: dst = op(src), or b - op(src) with b given
+  int active_apply(int which, double *dst, const double *src, const double *b);
+  int apply_on(const DeviceLevel &lv, int which01, const CoeffData &cd, const double *x, const EpiArgs &e);
+  int interface_up_into_defect(int which, int l);
+  int vcycle_adaptive(int which, double *dst, const double *src);
   CoeffData active;
   FaceTerm faces;   // free-surface stabilisation faces of the active Stokes operator
   void free_faces() {
@@ -255,7 +281,7 @@ struct agmg_ctx {
     return {(size_t)lv.n_dofs_p(), (size_t)lv.n_owned_p, (size_t)lv.n_owned_p, 0};
   }
   Span span_up() const {
-    const DeviceLevel &lv = L.back();
+    const DeviceLevel &lv = ad.on ? ad.act : L.back();
     const size_t nu = lv.n_dofs_v(), ou = (size_t)lv.n_owned_v * lv.dim;
     return {nu + (size_t)lv.n_dofs_p(), ou + (size_t)lv.n_owned_p, ou, nu - ou};
   }
@@ -267,7 +293,15 @@ struct agmg_ctx {
   static constexpr size_t COARSE_HOST_MAX_DOFS = 600;
   bool coarse_host(int which) const { return opt.coarse_on_host && !dist() && size_of(which, 0) <= COARSE_HOST_MAX_DOFS; }
   DeviceLevel &fin() { return L.back(); }
+  // the active mesh: the finest level (uniform refinement) or the tables set with agmg_set_level(AGMG_ACTIVE, desc)
+  DeviceLevel &act() { return ad.on ? ad.act : L.back(); }
+  const DeviceLevel &act() const { return ad.on ? ad.act : L.back(); }
   const CoeffData &active_coeff() { return active.set ? active : fin().coeff; }
+  Span span_act(int which) const {
+    const DeviceLevel &lv = act();
+    if (which == 0) { const size_t o = (size_t)lv.n_owned_v * lv.dim; return {(size_t)lv.n_dofs_v(), o, o, 0}; }
+    return {(size_t)lv.n_dofs_p(), (size_t)lv.n_owned_p, (size_t)lv.n_owned_p, 0};
+  }
   size_t size_of(int which, int l) const { return which == 0 ? (size_t)L[l].n_dofs_v() : (size_t)L[l].n_dofs_p(); }
 
   template <class T> int dalloc(T **p, size_t n) {
@@ -769,11 +803,14 @@ int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std
 int agmg_ctx::ensure_workspace() {
   size_t nu = 0, np = 0;
   const int dim = opt.dim, NV = ipow(3, dim), NP = ipow(2, dim);
-  for (auto &l : L) {
+  auto grow = [&](const DeviceLevel &l) {
     nu = std::max(nu, (size_t)NV * l.cstride * dim);
     nu = std::max(nu, l.bk.n_partial_slots * 3);
     np = std::max(np, (size_t)NP * l.cstride * dim);
-  }
+  };
+  for (auto &l : L) grow(l);
+  for (auto &l : ad.Lb) if (l.set) grow(l);
+  if (ad.on) grow(ad.act);
   if (nu > slots_u_cap) { dfree(slots_u); CHECK(dalloc(&slots_u, nu)); slots_u_cap = nu; }
   if (np > slots_p_cap) { dfree(slots_p); CHECK(dalloc(&slots_p, np)); slots_p_cap = np; }
   if (!dot_partials) {
@@ -803,7 +840,7 @@ int agmg_ctx::ensure_mg_vectors() {
 }
 
 int agmg_ctx::get_vec(size_t idx, double **p) {
-  const size_t n = (size_t)fin().n_dofs_v() + fin().n_dofs_p();
+  const size_t n = (size_t)act().n_dofs_v() + act().n_dofs_p();
   while (pool.size() <= idx) {
     double *v;
     CHECK(dalloc(&v, n));
@@ -942,18 +979,51 @@ int agmg_ctx::ensure_transfers() {
     const HostLevel &HF = H[l];
     if (HF.parent.empty()) { set_error("level " + std::to_string(l) + " has no parent_cell/child_index table"); return -1; }
     const DeviceLevel &C = L[l - 1];
-    std::vector<uint32_t> children((size_t)nch * C.cstride, 0xFFFFFFFFu);
+    std::vector<uint32_t> children((size_t)nch * C.cstride, NO_CHILD);
     for (int f = 0; f < F.n_cells; ++f) {
       const int p = HF.parent[f], ch = HF.child[f];
       if (p < 0 || p >= C.n_cells || ch >= nch) { set_error("bad parent_cell/child_index"); return -1; }
       children[(size_t)ch * C.cstride + p] = f;
     }
-    for (int p = 0; p < C.n_cells; ++p)
-      for (int ch = 0; ch < nch; ++ch)
-        if (children[(size_t)ch * C.cstride + p] == 0xFFFFFFFFu) { set_error("parent cell without 2^dim children (adaptive meshes: SURVEY.md 8f1)"); return -1; }
+    // a coarse cell has all its children or (local smoothing on an adaptive mesh: the cell is active on its level) none
+    for (int p = 0; p < C.n_cells; ++p) {
+      int n_kids = 0;
+      for (int ch = 0; ch < nch; ++ch) n_kids += children[(size_t)ch * C.cstride + p] != NO_CHILD;
+      if (n_kids != nch && !(n_kids == 0 && ad.on)) { set_error("parent cell without 2^dim children (cells that are active on a coarse level need the active mesh set with AGMG_ACTIVE first)"); return -1; }
+    }
     for (int p = C.n_cells; p < C.cstride; ++p)
       for (int ch = 0; ch < nch; ++ch) children[(size_t)ch * C.cstride + p] = 0;
-    CHECK(upload(&F.childrenT, children));
+    // The kernels walk every coarse cell.  A cell without children is given child 0 of the level in the DEVICE table (a
+    // valid cell): the prolongation writes a fine node only from its designated parent, which such a cell never is, and
+    // what the restriction leaves in its slots is never pulled (tables below).
+    bool childless = false;
+    std::vector<uint8_t> refined(C.n_cells, 1);
+    std::vector<uint32_t> children_dev(children);
+    for (int p = 0; p < C.n_cells; ++p)
+      if (children[p] == NO_CHILD) {
+        childless = true;
+        refined[p] = 0;
+        for (int ch = 0; ch < nch; ++ch) children_dev[(size_t)ch * C.cstride + p] = 0;
+      }
+    if (ad.on)
+      for (int vel = 0; vel < 2; ++vel) {
+        dfree(ad.rpull_ptr[vel ? 0 : 1][l]); dfree(ad.rpull_list[vel ? 0 : 1][l]);
+        if (!childless) continue;
+        const int nloc = ipow(vel ? 3 : 2, dim), nn = vel ? C.n_nodes_v : C.n_nodes_p;
+        const std::vector<uint32_t> &cnc = vel ? H[l - 1].cnv : H[l - 1].cnp;
+        std::vector<uint32_t> ptr((size_t)nn + 1, 0), list;
+        for (int p = 0; p < C.n_cells; ++p)
+          if (refined[p]) for (int a = 0; a < nloc; ++a) ++ptr[cnc[(size_t)p * nloc + a] + 1];
+        for (int i = 0; i < nn; ++i) ptr[i + 1] += ptr[i];
+        list.resize(ptr[nn]);
+        std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int p = 0; p < C.n_cells; ++p)
+          if (refined[p]) for (int a = 0; a < nloc; ++a) list[fill[cnc[(size_t)p * nloc + a]]++] = (uint32_t)((size_t)a * C.cstride + p);
+        if (list.empty()) list.push_back(0);
+        CHECK(upload(&ad.rpull_ptr[vel ? 0 : 1][l], ptr));
+        CHECK(upload(&ad.rpull_list[vel ? 0 : 1][l], list));
+      }
+    CHECK(upload(&F.childrenT, children_dev));
     F.bytes_transfer = children.size() * 4;
     for (int vel = 0; vel < 2; ++vel) {
       const int K = vel ? 2 : 1, n1 = K + 1, nf = 2 * K + 1, nloc = ipow(n1, dim);
@@ -968,6 +1038,7 @@ int agmg_ctx::ensure_transfers() {
       for (int p = 0; p < C.n_cells; ++p)
         for (int ch = 0; ch < nch; ++ch) {
           const uint32_t f = children[(size_t)ch * C.cstride + p];
+          if (f == NO_CHILD) continue;   // (host table: cells without children take no part)
           for (int i = 0; i < nloc; ++i) {
             int rem = i, pidx = 0, stride = 1;
             for (int d = 0; d < dim; ++d) {
@@ -1024,8 +1095,103 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
   return launch_pull_p(stream, lv, slots_p, 1, e, PH_OWNED);
 }
 
+// one-rank level operators on given tables: which01 0 = A block, 1 = mass
+int agmg_ctx::apply_on(const DeviceLevel &lv, int which01, const CoeffData &cd, const double *x, const EpiArgs &e) {
+  if (which01 == 0) return op_velocity(lv, cd, AGMG_OP_A, x, nullptr, e);
+  if (mass_ell(lv, cd)) return launch_mass_ell(stream, lv, cd, x, e);
+  CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
+  return launch_pull_p(stream, lv, slots_p, 1, e);
+}
+
+// Operators of the active mesh of an adaptive context.  MatrixFree resolves the hanging-node constraints when it reads
+// cell values and applies their transpose when it writes (read_dof_values / distribute_local_to_global); constrained
+// rows are identity rows: y = C^T A C x around the device operators, which treat every node as its own DoF.
+// FIRST SLICE: C and C^T are applied on the host (the vector crosses PCIe twice per application); the cell work, the
+// smoothers and the transfers run in the device kernels of the uniform path.  Device-side gather kernels for the two
+// CSRs are the next step.
+// src: [u], [p] or [u; p] as `which` asks; b != NULL: dst = b - op(src).
+int agmg_ctx::active_apply(int which, double *dst, const double *src, const double *b) {
+  const DeviceLevel &lv = ad.act;
+  const HostLevel &hl = ad.hact;
+  const CoeffData &cd = active_coeff();
+  const int dim = lv.dim;
+  const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
+  const bool has_u = which != AGMG_OP_MASS, has_p = which != AGMG_OP_A;
+  const size_t poff = has_u ? nu : 0, n = (has_u ? nu : 0) + (has_p ? np : 0);
+  if (ad.xres_cap < nu + np) { dfree(ad.xres); CHECK(dalloc(&ad.xres, nu + np)); ad.xres_cap = nu + np; }
+  double *xr = ad.xres;
+  std::vector<double> &hx = ad.hx, &hy = ad.hy;
+  hx.resize(n); hy.resize(n);
+  auto con = [&](int sp, uint32_t node, int comp) { return sp == 0 ? ((hl.cmask[0][node] >> comp) & 1) != 0 : (hl.cmask[1][node] & 1) != 0; };
+  CHECK(d2h(hx.data(), src, n));
+  std::vector<double> src_h[2];   // the entries of the hanging nodes as they came in (identity rows)
+  auto resolve = [&](int sp, size_t off, int nc) {
+    src_h[sp].resize(hl.hang_n[sp].size() * nc);
+    for (size_t i = 0; i < hl.hang_n[sp].size(); ++i)
+      for (int comp = 0; comp < nc; ++comp) {
+        double v = 0;
+        for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k)
+          if (!con(sp, hl.hang_m[sp][k], comp)) v += hl.hang_w[sp][k] * hx[off + (size_t)hl.hang_m[sp][k] * nc + comp];
+        double &slot = hx[off + (size_t)hl.hang_n[sp][i] * nc + comp];
+        src_h[sp][i * nc + comp] = slot;
+        slot = v;
+      }
+  };
+  auto distribute = [&](int sp, size_t off, int nc) {
+    for (size_t i = 0; i < hl.hang_n[sp].size(); ++i) {
+      const uint32_t h = hl.hang_n[sp][i];
+      for (int comp = 0; comp < nc; ++comp) {
+        if (!con(sp, h, comp))
+          for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k)
+            if (!con(sp, hl.hang_m[sp][k], comp)) hy[off + (size_t)hl.hang_m[sp][k] * nc + comp] += hl.hang_w[sp][k] * hy[off + (size_t)h * nc + comp];
+        hy[off + (size_t)h * nc + comp] = src_h[sp][i * nc + comp];
+      }
+    }
+  };
+  if (has_u) resolve(0, 0, dim);
+  if (has_p) resolve(1, poff, 1);
+  CHECK(h2d(xr, hx.data(), n));
+  EpiArgs e;
+  e.epi = EPI_STORE; e.dst = dst; e.x = xr;
+  switch (which) {
+    case AGMG_OP_A: CHECK(op_velocity(lv, cd, AGMG_OP_A, xr, nullptr, e)); break;
+    case AGMG_OP_MASS:
+      CHECK(launch_mass_cells(stream, lv, cd, xr, slots_p));
+      CHECK(launch_pull_p(stream, lv, slots_p, 1, e));
+      break;
+    case AGMG_OP_STOKES: {
+      EpiArgs ep = e;
+      ep.dst = dst + nu; ep.x = xr + nu;
+      CHECK(op_velocity(lv, cd, AGMG_OP_STOKES, xr, xr + nu, e, &ep));
+      break;
+    }
+    default:
+      CHECK(op_velocity(lv, cd, AGMG_OP_BT, nullptr, xr + nu, e));
+      CHECK(vec_set(stream, dst + nu, 0.0, np));
+  }
+  CHECK(d2h(hy.data(), dst, n));
+  if (has_u) distribute(0, 0, dim);
+  if (which == AGMG_OP_MASS || which == AGMG_OP_STOKES) distribute(1, poff, 1);   // (B^T writes no pressure rows)
+  CHECK(h2d(dst, hy.data(), n));
+  if (b) CHECK(vec_lincomb(stream, dst, 1.0, b, -1.0, dst, n));
+  return 0;
+}
+
 // dst = b - B^T p on the active mesh (velocity rows; stokes_matrix_free.h:299-303)
 int agmg_ctx::bt_residual(double *dst, const double *b, const double *p) {
+  if (ad.on) {
+    // [0; p] through the B^T operator of the active mesh (the identity rows of the hanging velocity nodes read the zero
+    // block), velocity rows kept; pool vector 4 is free while the block preconditioner forms this residual
+    const DeviceLevel &la = ad.act;
+    const size_t nu = la.n_dofs_v(), np = la.n_dofs_p();
+    double *in, *out;
+    CHECK(get_vec(3, &in)); CHECK(get_vec(4, &out));
+    CHECK(vec_set(stream, in, 0.0, nu));
+    CHECK(vec_copy(stream, in + nu, p, np));
+    CHECK(active_apply(AGMG_OP_BT, out, in, nullptr));
+    if (b) return vec_lincomb(stream, dst, 1.0, b, -1.0, out, nu);
+    return vec_copy(stream, dst, out, nu);
+  }
   const DeviceLevel &lv = fin();
   EpiArgs e;
   e.epi = b ? EPI_RESID : EPI_STORE; e.dst = dst; e.b = b; e.x = nullptr;
@@ -1050,6 +1216,13 @@ int agmg_ctx::restrict_to(int which, int l, const double *src_fine, const EpiArg
   double *slots = vel ? slots_u : slots_p;
   if (dist()) CHECK(update_ghosts(vel ? F.xv : F.xp, src_fine));
   CHECK(launch_restrict_cells(stream, F, C, vel, src_fine, slots));
+  if (ad.on && ad.rpull_ptr[vel ? 0 : 1][l]) {
+    // local smoothing: the slots of the coarse cells without children hold nothing to pull (ensure_transfers)
+    DeviceLevel Cr = C;
+    if (vel) { Cr.pull_ptr_v = ad.rpull_ptr[0][l]; Cr.pull_list_v = ad.rpull_list[0][l]; }
+    else { Cr.pull_ptr_p = ad.rpull_ptr[1][l]; Cr.pull_list_p = ad.rpull_list[1][l]; }
+    return vel ? launch_pull_v(stream, Cr, slots, e) : launch_pull_p(stream, Cr, slots, 1, e);
+  }
   if (!dist()) return vel ? launch_pull_v(stream, C, slots, e) : launch_pull_p(stream, C, slots, 1, e);
   CHECK(vel ? launch_pull_v(stream, C, slots, e, PH_GHOST) : launch_pull_p(stream, C, slots, 1, e, PH_GHOST));
   CHECK(compress(vel ? C.xv : C.xp));
@@ -1064,6 +1237,7 @@ int agmg_ctx::prolongate_from(int which, int l, double *dst_fine, const double *
 
 // Stokes operator on the active mesh; epilogue kind/b taken from eu_in (STORE or RESID)
 int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst) {
+  if (ad.on) return active_apply(AGMG_OP_STOKES, dst, src, eu_in.epi == EPI_RESID ? eu_in.b : nullptr);
   const DeviceLevel &lv = fin();
   const size_t nu = lv.n_dofs_v();
   EpiArgs eu = eu_in, ep = eu_in;
@@ -1312,6 +1486,23 @@ int agmg_ctx::level_v_step(int which, int l) {
   if (l == 0) return coarse_solve(which);
   const DeviceLevel &F = L[l];
   const int sm_steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  if (has_edge(l)) {
+    // Local smoothing, a level with a refinement edge (Multigrid::level_v_step with set_edge_matrices(interface,
+    // interface), local_smoothing.cc:1045, 1053).  The smoother leaves the edge entries of the solution at zero (identity
+    // rows, zero defect there), so matrix->vmult plus edge_out->vmult_add (vmult_interface_down: the edge rows of the
+    // operator applied to the other entries) is ONE application of the operator with the boundary rows alone constrained.
+    CHECK(smoother_apply(which, l, mg_def[which][l]));
+    EpiArgs e;
+    e.epi = EPI_RESID; e.dst = mg_t[which][l]; e.b = mg_def[which][l]; e.x = mg_sol[which][l];
+    CHECK(apply_on(ad.Lb[l], which, ad.Lb[l].coeff, mg_sol[which][l], e));
+    EpiArgs er;   // (the defect of the coarser level already holds what copy_to_mg put there: restrict_and_add)
+    er.epi = EPI_ADD; er.dst = mg_def[which][l - 1]; er.x = nullptr;
+    CHECK(restrict_to(which, l, mg_t[which][l], er));
+    CHECK(level_v_step(which, l - 1));
+    CHECK(prolongate_from(which, l, mg_sol[which][l], mg_sol[which][l - 1]));
+    CHECK(interface_up_into_defect(which, l));
+    return smoother_smooth(which, l, mg_def[which][l]);
+  }
   if (which == 1 && fused_mass(l) && sm_steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
     // pre-smoothing and the residual behind it in one launch
     SmootherProgram p;
@@ -1329,9 +1520,9 @@ int agmg_ctx::level_v_step(int which, int l) {
     CHECK(apply_level(which, l, F.coeff, mg_sol[which][l], e));
   }
   }
-  {  // defect[l-1] = R t   (coarse Dirichlet rows dropped)
+  {  // defect[l-1] = R t   (coarse Dirichlet rows dropped); adaptive contexts: += (copy_to_mg filled the coarser defect)
     EpiArgs e;
-    e.epi = EPI_STORE; e.dst = mg_def[which][l - 1]; e.x = nullptr;
+    e.epi = ad.on ? EPI_ADD : EPI_STORE; e.dst = mg_def[which][l - 1]; e.x = nullptr;
     CHECK(restrict_to(which, l, mg_t[which][l], e));
   }
   CHECK(level_v_step(which, l - 1));
@@ -1339,8 +1530,57 @@ int agmg_ctx::level_v_step(int which, int l) {
   return smoother_smooth(which, l, mg_def[which][l]);
 }
 
+// edge_in->Tvmult (vmult_interface_up) after the coarse-grid correction: defect -= (rows off the edge of the operator with
+// the boundary rows alone constrained) applied to the edge entries of the solution
+int agmg_ctx::interface_up_into_defect(int which, int l) {
+  const DeviceLevel &B = ad.Lb[l];
+  const size_t n = size_of(which, l);
+  const int nn = which == 0 ? B.n_nodes_v : B.n_nodes_p, nc = which == 0 ? B.dim : 1;
+  double *xe = mg_tmp[which][l], *y = mg_t[which][l];
+  CHECK(vec_copy(stream, xe, mg_sol[which][l], n));
+  CHECK(vec_zero_constrained(stream, xe, ad.notedge[which][l], nn, nc));
+  EpiArgs e;
+  e.epi = EPI_STORE; e.dst = y; e.x = xe;
+  CHECK(apply_on(B, which, B.coeff, xe, e));
+  CHECK(vec_zero_constrained(stream, y, ad.edge[which][l], nn, nc));
+  CHECK(vec_zero_constrained(stream, y, which == 0 ? B.cmask_v : B.cmask_p, nn, nc));   // (apply_add writes no boundary rows)
+  return vec_axpy(stream, mg_def[which][l], -1.0, y, n);
+}
+
+// PreconditionMG::vmult of an adaptive context: copy_to_mg fills the defect of EVERY level through its copy table (the
+// cells that are active on the level), the cycle runs from the finest level, copy_from_mg gathers the solutions.
+// FIRST SLICE: the two copies are host loops over the tables (see active_apply).
+int agmg_ctx::vcycle_adaptive(int which, double *dst, const double *src) {
+  const int top = nl() - 1, nc = which == 0 ? opt.dim : 1;
+  const size_t n = which == 0 ? (size_t)ad.act.n_dofs_v() : (size_t)ad.act.n_dofs_p();
+  std::vector<double> &hx = ad.hx, &hy = ad.hy;
+  hx.resize(n);
+  CHECK(d2h(hx.data(), src, n));
+  for (int l = 0; l <= top; ++l) {
+    const size_t nl_ = size_of(which, l);
+    hy.assign(nl_, 0.0);
+    const std::vector<uint32_t> &ca = ad.copy_act[which][l], &cl = ad.copy_lev[which][l];
+    for (size_t i = 0; i < ca.size(); ++i)
+      for (int c = 0; c < nc; ++c) hy[(size_t)cl[i] * nc + c] = hx[(size_t)ca[i] * nc + c];
+    CHECK(h2d(mg_def[which][l], hy.data(), nl_));
+  }
+  CHECK(level_v_step(which, top));
+  hx.assign(n, 0.0);
+  for (int l = 0; l <= top; ++l) {
+    const std::vector<uint32_t> &ca = ad.copy_act[which][l], &cl = ad.copy_lev[which][l];
+    if (ca.empty()) continue;
+    const size_t nl_ = size_of(which, l);
+    hy.resize(nl_);
+    CHECK(d2h(hy.data(), mg_sol[which][l], nl_));
+    for (size_t i = 0; i < ca.size(); ++i)
+      for (int c = 0; c < nc; ++c) hx[(size_t)ca[i] * nc + c] = hy[(size_t)cl[i] * nc + c];
+  }
+  return h2d(dst, hx.data(), n);
+}
+
 // PreconditionMG::vmult on device vectors of the active (= finest) mesh
 int agmg_ctx::vcycle(int which, double *dst, const double *src) {
+  if (ad.on) return vcycle_adaptive(which, dst, src);
   const int top = nl() - 1;
   VGraph &g = vgraph[which];
   if (use_graphs && !dist() && g.state > 0) {
@@ -1743,7 +1983,7 @@ int agmg_ctx::solver_bicgstab(const std::function<int(double *, const double *)>
 
 // BlockSchurGMGPreconditioner::vmult (stokes_matrix_free.h:237-354) on device block vectors
 int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *status) {
-  const DeviceLevel &lv = fin();
+  const DeviceLevel &lv = act();
   const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
   const int top = nl() - 1;
   double *dst_u = dst, *dst_p = dst + nu;
@@ -1752,19 +1992,20 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
   CHECK(get_vec(0, &utmp));
   if (expensive) {
     double nrm;
-    CHECK(norm(src_p, span_of(1, top), &nrm));
+    CHECK(norm(src_p, span_act(1), &nrm));
     CHECK(vec_set(stream, dst_p, 0.0, np));
     if (nrm > 1e-50) {
       double *w0, *w1;
       CHECK(get_vec(1, &w0)); CHECK(get_vec(2, &w1));
       double *work[4] = {w0, w0 + np, w1, w1 + np};  // np <= nu: two pressure vectors fit one block vector
       auto Aop = [&](double *d, const double *s) {
+        if (ad.on) return active_apply(AGMG_OP_MASS, d, s, nullptr);
         EpiArgs e; e.epi = EPI_STORE; e.dst = d; e.x = s;
         return apply_level(1, top, active_coeff(), s, e);
       };
       auto Pop = [&](double *d, const double *s) { return vcycle(1, d, s); };
       int its; bool conv;
-      CHECK(solver_cg(Aop, Pop, dst_p, src_p, span_of(1, top), 100, nrm * opt.S_block_tolerance, work, &its, &conv));
+      CHECK(solver_cg(Aop, Pop, dst_p, src_p, span_act(1), 100, nrm * opt.S_block_tolerance, work, &its, &conv));
       nS += its;
       if (!conv && status) *status = -2;
     }
@@ -1776,7 +2017,7 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
   CHECK(bt_residual(utmp, src_u, dst_p));  // utmp = src_u - B^T dst_p
   if (expensive) {
     double nrm;
-    CHECK(norm(utmp, span_of(0, top), &nrm));
+    CHECK(norm(utmp, span_act(0), &nrm));
     CHECK(vec_set(stream, dst_u, 0.0, nu));
     double *w[7];
     for (int i = 0; i < 4; ++i) CHECK(get_vec(1 + i, &w[i]));
@@ -1789,15 +2030,16 @@ int agmg_ctx::precondition(bool expensive, double *dst, const double *src, int *
       for (int i = 0; i < 3; ++i) w[4 + i] = bicg_pool[i];
     }
     auto Aop = [&](double *d, const double *s) {
+      if (ad.on) return active_apply(AGMG_OP_A, d, s, nullptr);
       EpiArgs e; e.epi = EPI_STORE; e.dst = d; e.x = s;
       return apply_level(0, top, active_coeff(), s, e);
     };
     auto Pop = [&](double *d, const double *s) { return vcycle(0, d, s); };
     int its; bool conv;
     if (opt.A_block_is_symmetric)
-      CHECK(solver_cg(Aop, Pop, dst_u, utmp, span_of(0, top), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
+      CHECK(solver_cg(Aop, Pop, dst_u, utmp, span_act(0), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
     else
-      CHECK(solver_bicgstab(Aop, Pop, dst_u, utmp, span_of(0, top), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
+      CHECK(solver_bicgstab(Aop, Pop, dst_u, utmp, span_act(0), 1000, nrm * opt.A_block_tolerance, w, &its, &conv));
     nA += its;
     if (!conv && status) *status = -3;
   } else {
@@ -2192,6 +2434,8 @@ void agmg_destroy(agmg_ctx *c) {
   (void)hipSetDevice(c->opt.device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &l : c->L) c->free_level(l);
+  for (int l = 0; l < (int)c->ad.Lb.size(); ++l) c->free_adaptive_level(l);
+  c->free_adaptive_active();
   c->free_coeff(c->active);
   c->dfree(c->slots_u); c->dfree(c->slots_p);
   for (auto &p : c->bicg_pool) c->dfree(p);
@@ -2227,19 +2471,15 @@ struct StepTimer {
 };
 }  // namespace
 
-int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
-  if (!c) { set_error("null context"); return -1; }
-  StepTimer tm;
-  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
-  if (level == AGMG_ACTIVE) {
-    if (d) { set_error("a separate active-mesh table is not supported: the active mesh must alias the finest level (uniformly refined meshes; adaptive = SURVEY.md 8f1)"); return -2; }
-    return 0;
-  }
-  if (level < 0 || level >= c->nl()) { set_error("bad level"); return -1; }
-  if (!d || d->n_cells <= 0 || !d->cell_nodes_v || !d->cell_nodes_p || !d->constrained_v) { set_error("incomplete level descriptor"); return -1; }
+// Tables of one mesh (a multigrid level, its boundary-rows-only twin on a level with a refinement edge, or the active mesh
+// of an adaptive context) with the constraint masks cmv / cmp.  primary: the level itself (exchange plan, global ids,
+// state flags of the context); the twins and the active mesh of adaptive contexts live on one rank.
+static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int level, const agmg_level_desc *d,
+                            const std::vector<uint8_t> &cmv, const std::vector<uint8_t> &cmp, bool primary, bool structured, StepTimer &tm) {
   const int dim = c->opt.dim, NV = ipow(3, dim), NP = ipow(2, dim);
-  if ((unsigned)d->n_nodes_v > NODE_MASK || (unsigned)d->n_nodes_p > NODE_MASK) { set_error("too many nodes for 29-bit indices"); return -1; }
-  const bool has_plan = d->n_owned_nodes_v != d->n_nodes_v || d->n_owned_nodes_p != d->n_nodes_p || d->n_neighbors != 0;
+  const bool has_plan = primary && (d->n_owned_nodes_v != d->n_nodes_v || d->n_owned_nodes_p != d->n_nodes_p || d->n_neighbors != 0);
+  static const std::vector<uint32_t> no_send_nodes;
+  auto send_nodes_of = [&](int w) -> const std::vector<uint32_t> & { return primary ? c->send_nodes_h[w][level] : no_send_nodes; };
   if (has_plan && c->dist()) {
     if (!c->comm_set) { set_error("set_level: bind the transport first (agmg_set_communicator)"); return -1; }
     if (d->n_neighbors < 0 || (d->n_neighbors > 0 && (!d->neighbor_rank || !d->send_offsets_v || !d->recv_offsets_v ||
@@ -2262,45 +2502,15 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     set_error("ghost nodes / neighbours given but world_size == 1");
     return -1;
   }
-  DeviceLevel &lv = c->L[level];
   c->free_level(lv);
-  if (level == c->nl() - 1) {   // face tables and the active coefficients refer to the cells of the active mesh
-    c->free_faces();
-    c->free_coeff(c->active);
-  }
-  HostLevel &hl = c->H[level];
   lv.dim = dim;
   lv.n_cells = d->n_cells; lv.n_nodes_v = d->n_nodes_v; lv.n_nodes_p = d->n_nodes_p;
   lv.cstride = (d->n_cells + 63) / 64 * 64;
   const size_t cs = lv.cstride;
   hl.cnv.assign(d->cell_nodes_v, d->cell_nodes_v + (size_t)lv.n_cells * NV);
   hl.cnp.assign(d->cell_nodes_p, d->cell_nodes_p + (size_t)lv.n_cells * NP);
-  std::vector<uint8_t> cmv(d->constrained_v, d->constrained_v + lv.n_nodes_v);
-  std::vector<uint8_t> cmp(lv.n_nodes_p, 0);
-  if (d->constrained_p) cmp.assign(d->constrained_p, d->constrained_p + lv.n_nodes_p);
-  const uint8_t vmask = (uint8_t)((1u << dim) - 1u);
-  for (auto &m : cmv) m &= vmask;
-  for (auto &m : cmp) m &= 1u;
-  for (int sp = 0; sp < 2; ++sp) {   // hanging-node constraints (first slice: one-level contexts, host-vector operators)
-    const int nh = sp == 0 ? d->n_hanging_v : d->n_hanging_p, nn = sp == 0 ? lv.n_nodes_v : lv.n_nodes_p;
-    const uint32_t *hn = sp == 0 ? d->hanging_nodes_v : d->hanging_nodes_p, *hm = sp == 0 ? d->hanging_master_v : d->hanging_master_p;
-    const int32_t *hp = sp == 0 ? d->hanging_ptr_v : d->hanging_ptr_p;
-    const double *hw = sp == 0 ? d->hanging_weight_v : d->hanging_weight_p;
-    hl.hang_n[sp].clear(); hl.hang_m[sp].clear(); hl.hang_ptr[sp].clear(); hl.hang_w[sp].clear();
-    hl.cmask[sp] = sp == 0 ? cmv : cmp;
-    if (nh <= 0) continue;
-    if (c->nl() != 1 || c->dist()) { set_error("hanging-node constraints: one-level, one-rank contexts only (first slice; SURVEY.md 8 f1)"); return -2; }
-    if (!hn || !hp || !hm || !hw) { set_error("incomplete hanging-node tables"); return -1; }
-    if (hp[0] != 0) { set_error("hanging_ptr must start at 0"); return -1; }
-    for (int i = 0; i < nh; ++i) if (hp[i + 1] < hp[i]) { set_error("hanging_ptr must be non-decreasing"); return -1; }
-    hl.hang_n[sp].assign(hn, hn + nh); hl.hang_ptr[sp].assign(hp, hp + nh + 1);
-    hl.hang_m[sp].assign(hm, hm + hp[nh]); hl.hang_w[sp].assign(hw, hw + hp[nh]);
-    std::vector<uint8_t> is_h(nn, 0);
-    for (uint32_t h : hl.hang_n[sp]) { if ((int)h >= nn) { set_error("hanging node out of range"); return -1; } is_h[h] = 1; }
-    for (uint32_t m : hl.hang_m[sp]) if ((int)m >= nn || is_h[m]) { set_error("hanging-node master out of range or hanging itself"); return -1; }
-  }
   lv.n_owned_v = lv.n_nodes_v; lv.n_owned_p = lv.n_nodes_p;
-  for (int w = 0; w < 2; ++w) c->send_nodes_h[w][level].clear();
+  if (primary) for (int w = 0; w < 2; ++w) c->send_nodes_h[w][level].clear();
   if (has_plan) {  // ghost exchange plans of the two node spaces
     lv.n_owned_v = d->n_owned_nodes_v; lv.n_owned_p = d->n_owned_nodes_p;
     for (int vel = 0; vel < 2; ++vel) {
@@ -2328,7 +2538,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
   }
   for (int vel = 0; vel < 2; ++vel) {
     const uint32_t *gn = vel ? d->global_nodes_v : d->global_nodes_p;
-    if (gn && c->dist()) {
+    if (gn && c->dist() && primary) {
       std::vector<uint32_t> g(gn, gn + (vel ? lv.n_nodes_v : lv.n_nodes_p));
       CHECK(c->upload(vel ? &lv.gid_v : &lv.gid_p, g));
       if (level == c->nl() - 1) c->gid_fin_h[vel] = g;
@@ -2339,7 +2549,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     const int nloc = vel ? NV : NP, nn = vel ? lv.n_nodes_v : lv.n_nodes_p;
     const std::vector<uint32_t> &cn = vel ? hl.cnv : hl.cnp;
     const std::vector<uint8_t> &cm = vel ? cmv : cmp;
-    const std::vector<uint32_t> &snh = c->send_nodes_h[vel ? 0 : 1][level];
+    const std::vector<uint32_t> &snh = send_nodes_of(vel ? 0 : 1);
     std::vector<uint32_t> T((size_t)nloc * cs);
     std::vector<uint32_t> ptr((size_t)nn + 1, 0), list((size_t)lv.n_cells * nloc + snh.size());
     {
@@ -2450,24 +2660,172 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
     hl.child.assign(d->child_index, d->child_index + lv.n_cells);
   }
   tm.lap("geometry", level);
-  CHECK(c->build_block_tables(lv, hl, cmv, c->send_nodes_h[0][level]));
+  CHECK(c->build_block_tables(lv, hl, cmv, send_nodes_of(0)));
   tm.lap("block tables", level);
   lv.bytes_tables += lv.bt.bytes;
-  if (c->use_bricks) {
+  if (c->use_bricks && structured) {   // (not for the partly refined meshes of adaptive contexts)
     CHECK(c->build_brick_tables(lv, hl, cmv));
     lv.bytes_tables += lv.bk.bytes;
   }
   CHECK(c->dalloc(&lv.inv_diag_A, (size_t)lv.n_dofs_v()));
   CHECK(c->dalloc(&lv.inv_diag_M, (size_t)lv.n_dofs_p()));
   lv.set = true;
-  if (level + 1 < c->nl()) c->L[level + 1].has_transfer = false;
+  return 0;
+}
+
+void agmg_ctx::free_adaptive_level(int l) {
+  if (l < (int)ad.Lb.size()) { free_level(ad.Lb[l]); ad.Hb[l] = HostLevel(); }
+  for (int w = 0; w < 2; ++w) {
+    if (l < (int)ad.edge[w].size()) { dfree(ad.edge[w][l]); dfree(ad.notedge[w][l]); }
+    if (l < (int)ad.copy_act[w].size()) { ad.copy_act[w][l].clear(); ad.copy_lev[w][l].clear(); }
+    for (int k = l; k <= l + 1; ++k)   // restriction tables that involve this level as the fine or the coarse one
+      if (k < (int)ad.rpull_ptr[w].size()) { dfree(ad.rpull_ptr[w][k]); dfree(ad.rpull_list[w][k]); }
+  }
+}
+void agmg_ctx::free_adaptive_active() {
+  free_level(ad.act);
+  ad.hact = HostLevel();
+  dfree(ad.xres);
+  ad.xres_cap = 0;
+  ad.on = false;
+}
+
+int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
+  if (!c) { set_error("null context"); return -1; }
+  StepTimer tm;
+  AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
+  CHECK(c->sync());
+  if (level == AGMG_ACTIVE && !d) {   // uniformly refined mesh: the active mesh is the finest level
+    if (c->ad.on) { c->free_adaptive_active(); c->free_faces(); c->free_coeff(c->active); }
+    return 0;
+  }
+  if (level != AGMG_ACTIVE && (level < 0 || level >= c->nl())) { set_error("bad level"); return -1; }
+  if (!d || d->n_cells <= 0 || !d->cell_nodes_v || !d->cell_nodes_p || !d->constrained_v) { set_error("incomplete level descriptor"); return -1; }
+  const int dim = c->opt.dim;
+  if ((unsigned)d->n_nodes_v > NODE_MASK || (unsigned)d->n_nodes_p > NODE_MASK) { set_error("too many nodes for 29-bit indices"); return -1; }
+  std::vector<uint8_t> cmv(d->constrained_v, d->constrained_v + d->n_nodes_v);
+  std::vector<uint8_t> cmp(d->n_nodes_p, 0);
+  if (d->constrained_p) cmp.assign(d->constrained_p, d->constrained_p + d->n_nodes_p);
+  const uint8_t vmask = (uint8_t)((1u << dim) - 1u);
+  for (auto &m : cmv) m &= vmask;
+  for (auto &m : cmp) m &= 1u;
+  const bool active = level == AGMG_ACTIVE;
+  if (active && c->dist()) { set_error("an active mesh with tables of its own (adaptive refinement): one-rank contexts only"); return -2; }
+  HostLevel &hl = active ? c->ad.hact : c->H[level];
+  // hanging-node constraints: on the active mesh of an adaptive context (resolved around the device operators), or on
+  // the single level of a one-level context (the first slice: resolved on the host around agmg_vmult)
+  HostLevel parsed;
+  for (int sp = 0; sp < 2; ++sp) {
+    const int nh = sp == 0 ? d->n_hanging_v : d->n_hanging_p, nn = sp == 0 ? d->n_nodes_v : d->n_nodes_p;
+    const uint32_t *hn = sp == 0 ? d->hanging_nodes_v : d->hanging_nodes_p, *hm = sp == 0 ? d->hanging_master_v : d->hanging_master_p;
+    const int32_t *hp = sp == 0 ? d->hanging_ptr_v : d->hanging_ptr_p;
+    const double *hw = sp == 0 ? d->hanging_weight_v : d->hanging_weight_p;
+    parsed.cmask[sp] = sp == 0 ? cmv : cmp;
+    if (nh <= 0) continue;
+    if (!active && (c->nl() != 1 || c->dist())) { set_error("hanging-node constraints belong to the active mesh (AGMG_ACTIVE) or to the level of a one-level, one-rank context"); return -2; }
+    if (!hn || !hp || !hm || !hw) { set_error("incomplete hanging-node tables"); return -1; }
+    if (hp[0] != 0) { set_error("hanging_ptr must start at 0"); return -1; }
+    for (int i = 0; i < nh; ++i) if (hp[i + 1] < hp[i]) { set_error("hanging_ptr must be non-decreasing"); return -1; }
+    parsed.hang_n[sp].assign(hn, hn + nh); parsed.hang_ptr[sp].assign(hp, hp + nh + 1);
+    parsed.hang_m[sp].assign(hm, hm + hp[nh]); parsed.hang_w[sp].assign(hw, hw + hp[nh]);
+    std::vector<uint8_t> is_h(nn, 0);
+    for (uint32_t h : parsed.hang_n[sp]) { if ((int)h >= nn || is_h[h]) { set_error("hanging node out of range or listed twice"); return -1; } is_h[h] = 1; }
+    for (uint32_t m : parsed.hang_m[sp]) if ((int)m >= nn || is_h[m]) { set_error("hanging-node master out of range or hanging itself"); return -1; }
+  }
+  // refinement edge and copy table of a level of local smoothing
+  bool any_edge = false;
+  std::vector<uint8_t> ev, ep;
+  if (!active && (d->refinement_edge_v || d->refinement_edge_p)) {
+    if (!d->refinement_edge_v || !d->refinement_edge_p) { set_error("refinement-edge masks come for both spaces"); return -1; }
+    ev.assign(d->refinement_edge_v, d->refinement_edge_v + d->n_nodes_v);
+    ep.assign(d->refinement_edge_p, d->refinement_edge_p + d->n_nodes_p);
+    for (uint8_t e : ev) any_edge |= e != 0;
+    for (uint8_t e : ep) any_edge |= e != 0;
+    if (any_edge && c->dist()) { set_error("refinement edges (local smoothing on adaptive meshes): one-rank contexts only"); return -2; }
+  }
+  if (!active && (d->n_copy_v > 0 || d->n_copy_p > 0)) {
+    if (c->dist()) { set_error("copy tables (local smoothing on adaptive meshes): one-rank contexts only"); return -2; }
+    for (int sp = 0; sp < 2; ++sp) {
+      const int nc = sp == 0 ? d->n_copy_v : d->n_copy_p, nn = sp == 0 ? d->n_nodes_v : d->n_nodes_p;
+      const uint32_t *ca = sp == 0 ? d->copy_active_v : d->copy_active_p, *cl = sp == 0 ? d->copy_level_v : d->copy_level_p;
+      if (nc < 0 || (nc > 0 && (!ca || !cl))) { set_error("incomplete copy tables"); return -1; }
+      std::vector<uint8_t> seen(nn, 0);
+      for (int i = 0; i < nc; ++i) {
+        if ((int)cl[i] >= nn || seen[cl[i]]) { set_error("copy table: level node out of range or listed twice"); return -1; }
+        seen[cl[i]] = 1;
+      }
+    }
+  }
+  if (active) {
+    c->free_adaptive_active();
+    c->free_faces();
+    c->free_coeff(c->active);
+  } else {
+    c->free_adaptive_level(level);
+    if (level == c->nl() - 1 && !c->ad.on) {   // face tables and the active coefficients refer to the cells of the active mesh
+      c->free_faces();
+      c->free_coeff(c->active);
+    }
+  }
+  DeviceLevel &lv = active ? c->ad.act : c->L[level];
+  std::vector<uint8_t> cmv_op = cmv, cmp_op = cmp;       // the masks of the level operator: boundary + refinement edge
+  if (any_edge) {
+    for (int i = 0; i < d->n_nodes_v; ++i) if (ev[i]) cmv_op[i] |= vmask;
+    for (int i = 0; i < d->n_nodes_p; ++i) if (ep[i]) cmp_op[i] |= 1u;
+  }
+  const bool structured = !active && !d->refinement_edge_v && d->n_copy_v <= 0;
+  CHECK(set_level_tables(c, lv, hl, active ? -1 : level, d, cmv_op, cmp_op, !active, structured, tm));
+  for (int sp = 0; sp < 2; ++sp) {
+    hl.hang_n[sp] = parsed.hang_n[sp]; hl.hang_m[sp] = parsed.hang_m[sp]; hl.hang_ptr[sp] = parsed.hang_ptr[sp]; hl.hang_w[sp] = parsed.hang_w[sp];
+    hl.cmask[sp] = parsed.cmask[sp];
+  }
+  if (!active) {
+    const int nl = c->nl();
+    agmg_ctx::Adaptive &ad = c->ad;
+    if ((int)ad.Lb.size() != nl) {
+      ad.Lb.resize(nl); ad.Hb.resize(nl);
+      for (int w = 0; w < 2; ++w) {
+        ad.edge[w].assign(nl, nullptr); ad.notedge[w].assign(nl, nullptr);
+        ad.copy_act[w].assign(nl, {}); ad.copy_lev[w].assign(nl, {});
+        ad.rpull_ptr[w].assign(nl, nullptr); ad.rpull_list[w].assign(nl, nullptr);
+      }
+    }
+    if (any_edge) {
+      // the twin with the boundary rows alone, and the masks that split a vector into edge and other entries
+      CHECK(set_level_tables(c, ad.Lb[level], ad.Hb[level], level, d, cmv, cmp, false, false, tm));
+      for (int w = 0; w < 2; ++w) {
+        const std::vector<uint8_t> &e = w == 0 ? ev : ep;
+        const uint8_t all = w == 0 ? vmask : (uint8_t)1;
+        std::vector<uint8_t> on(e.size()), off(e.size());
+        for (size_t i = 0; i < e.size(); ++i) { on[i] = e[i] ? all : 0; off[i] = e[i] ? 0 : all; }
+        CHECK(c->upload(&ad.edge[w][level], on));
+        CHECK(c->upload(&ad.notedge[w][level], off));
+      }
+    }
+    for (int w = 0; w < 2; ++w) {
+      const int nc = w == 0 ? d->n_copy_v : d->n_copy_p;
+      if (nc <= 0) continue;
+      const uint32_t *ca = w == 0 ? d->copy_active_v : d->copy_active_p, *cl = w == 0 ? d->copy_level_v : d->copy_level_p;
+      ad.copy_act[w][level].assign(ca, ca + nc);
+      ad.copy_lev[w][level].assign(cl, cl + nc);
+    }
+    if (level + 1 < nl) c->L[level + 1].has_transfer = false;
+    lv.has_transfer = false;
+  } else {
+    // (the hanging-node CSRs stay on the host, in ad.hact: first slice, see active_apply)
+    agmg_ctx::Adaptive &ad = c->ad;
+    ad.on = true;
+  }
   c->mg_alloc = false; c->diag_ready = false; c->smoothers_ready = false;
+  c->free_graphs();
   for (auto &p : c->pool) c->dfree(p);
   c->pool.clear();
   for (auto &p : c->bicg_pool) c->dfree(p);
   c->bicg_pool.clear();
   return 0;
 }
+
+static int set_coefficients_on(agmg_ctx *c, DeviceLevel &lv, CoeffData &cd, bool is_active, const agmg_cell_data *d);
 
 int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
   if (!c || !d) { set_error("null argument"); return -1; }
@@ -2485,9 +2843,19 @@ int agmg_set_coefficients(agmg_ctx *c, int level, const agmg_cell_data *d) {
     }
   }
   if (level != AGMG_ACTIVE && (level < 0 || level >= c->nl())) { set_error("bad level"); return -1; }
-  DeviceLevel &lv = level == AGMG_ACTIVE ? c->fin() : c->L[level];
-  if (!lv.set) { set_error("set_coefficients before set_level"); return -1; }
-  CoeffData &cd = level == AGMG_ACTIVE ? c->active : lv.coeff;
+  DeviceLevel &lv0 = level == AGMG_ACTIVE ? c->act() : c->L[level];
+  if (!lv0.set) { set_error("set_coefficients before set_level"); return -1; }
+  if (d->n_q_viscosity != 1 && d->n_q_viscosity != ipow(3, c->opt.dim)) { set_error("n_q_viscosity must be 1 or 3^dim"); return -1; }
+  if (!d->viscosity) { set_error("viscosity table missing"); return -1; }
+  CHECK(set_coefficients_on(c, lv0, level == AGMG_ACTIVE ? c->active : lv0.coeff, level == AGMG_ACTIVE, d));
+  // a level with a refinement edge: its twin with the boundary rows alone carries the same coefficients
+  if (level != AGMG_ACTIVE && c->has_edge(level)) CHECK(set_coefficients_on(c, c->ad.Lb[level], c->ad.Lb[level].coeff, false, d));
+  c->diag_ready = false; c->smoothers_ready = false;
+  return 0;
+}
+
+static int set_coefficients_on(agmg_ctx *c, DeviceLevel &lv, CoeffData &cd, bool is_active, const agmg_cell_data *d) {
+  const int level = is_active ? AGMG_ACTIVE : 0;
   const int NQ = ipow(3, c->opt.dim);
   if (d->n_q_viscosity != 1 && d->n_q_viscosity != NQ) { set_error("n_q_viscosity must be 1 or 3^dim"); return -1; }
   if (!d->viscosity) { set_error("viscosity table missing"); return -1; }
@@ -2612,6 +2980,7 @@ int agmg_set_free_surface_faces(agmg_ctx *c, const agmg_face_data *d) {
   if (d->n_faces < 0 || !d->face_cell || !d->face_number || !d->stabilization_term) { set_error("free-surface face tables missing"); return -1; }
   if ((d->normal == nullptr) != (d->jxw == nullptr)) { set_error("face normal and jxw come together"); return -1; }
   if (c->L.empty() || !c->fin().set) { set_error("set_free_surface_faces before set_level"); return -1; }
+  if (c->ad.on) { set_error("free-surface faces are not built for adaptive contexts (SURVEY.md 8 f1)"); return -2; }
   const DeviceLevel &lv = c->fin();
   const HostLevel &hl = c->H[c->nl() - 1];
   const int dim = lv.dim, NV = ipow(3, dim), NF = ipow(3, dim - 1), NQF = NF, nf = d->n_faces;
@@ -2709,7 +3078,7 @@ int agmg_compute_diagonals(agmg_ctx *c) {
 
 static int vmult_sizes(agmg_ctx *c, int which, int level, size_t *n) {
   if (level != AGMG_ACTIVE && (level < 0 || level >= c->nl())) { set_error("bad level"); return -1; }
-  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->fin() : c->L[level];
+  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->act() : c->L[level];
   const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
   switch (which) {
     case AGMG_OP_STOKES: case AGMG_OP_BT: *n = nu + np; break;
@@ -2722,6 +3091,7 @@ static int vmult_sizes(agmg_ctx *c, int which, int level, size_t *n) {
 
 // the operator application itself, on the context's current slot buffers (slots_u, slots_p)
 static int vmult_device_impl(agmg_ctx *c, int which, int level, double *dst, const double *src) {
+  if (level == AGMG_ACTIVE && c->ad.on) return c->active_apply(which, dst, src, nullptr);
   const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
   const DeviceLevel &lv = c->L[l];
   const CoeffData &cd = level == AGMG_ACTIVE ? c->active_coeff() : lv.coeff;
@@ -2773,6 +3143,7 @@ int agmg_vmult_device_noalloc(agmg_ctx *c, int which, int level, double *dst, co
   if (c->has_hanging()) { set_error("agmg_vmult_device_noalloc: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   if (!dst || !src) { set_error("null vector"); return -1; }
   if (c->dist()) { set_error("agmg_vmult_device_noalloc: one-rank contexts only (the ghost exchange stages through buffers it allocates)"); return -2; }
+  if (c->ad.on) { set_error("agmg_vmult_device_noalloc: not in adaptive contexts (their constraint handling stages through host vectors)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
@@ -2875,6 +3246,7 @@ int agmg_vmult(agmg_ctx *c, int which, int level, double *dst, const double *src
 int agmg_rhs_correction(agmg_ctx *c, const double *u0_h, double *rhs_h) {
   if (!c || !u0_h || !rhs_h) { set_error("null argument"); return -1; }
   if (c->has_hanging()) { set_error("agmg_rhs_correction: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
+  if (c->ad.on) { set_error("agmg_rhs_correction: not built for adaptive contexts (inhomogeneous constraints next to hanging nodes; SURVEY.md 8 f1)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   const DeviceLevel &lv = c->fin();
   if (!lv.set || !c->active_coeff().set) { set_error("rhs_correction: active mesh tables / coefficients not set"); return -1; }
@@ -2990,7 +3362,7 @@ int agmg_vcycle(agmg_ctx *c, int which, double *dst, const double *src) {
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   if (!c->smoothers_ready) CHECK(c->setup_smoothers());
   const int w = which == AGMG_OP_A ? 0 : 1;
-  const size_t n = c->size_of(w, c->nl() - 1);
+  const size_t n = w == 0 ? (size_t)c->act().n_dofs_v() : (size_t)c->act().n_dofs_p();
   double *ds, *dd;
   CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
   int rc = c->h2d(ds, src, n);
@@ -3005,7 +3377,7 @@ int agmg_precondition(agmg_ctx *c, int expensive, double *dst, const double *src
   if (c->has_hanging()) { set_error("agmg_precondition: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   if (!c->smoothers_ready) CHECK(c->setup_smoothers());
-  const size_t n = (size_t)c->fin().n_dofs_v() + c->fin().n_dofs_p();
+  const size_t n = (size_t)c->act().n_dofs_v() + c->act().n_dofs_p();
   double *ds, *dd;
   CHECK(c->dalloc(&ds, n)); CHECK(c->dalloc(&dd, n));
   int status = 0;
@@ -3028,14 +3400,21 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
   CHECK(c->sync());
   const double t_setup = now_s();
   rep->setup_seconds = t_setup - t_begin;
-  const DeviceLevel &lv = c->fin();
+  const DeviceLevel &lv = c->act();
   const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p(), n = nu + np;
   const agmg_ctx::Span sp = c->span_up();
   hipStream_t st = c->stream;
+  CHECK(c->ensure_workspace());
   // pool layout: 0..4 preconditioner scratch, 5 rhs, 6 x, 7 tmp, 8 x0, 9.. Krylov
   double *rhs, *x, *tmp, *x0;
   CHECK(c->get_vec(5, &rhs)); CHECK(c->get_vec(6, &x)); CHECK(c->get_vec(7, &tmp)); CHECK(c->get_vec(8, &x0));
   CHECK(c->h2d(rhs, rhs_h, n));
+  if (c->ad.on) {   // (hanging nodes are constrained entries too: zero in the start vector, identity rows in the operator)
+    std::vector<double> xs(x_h, x_h + n);
+    for (uint32_t h : c->ad.hact.hang_n[0]) for (int k = 0; k < lv.dim; ++k) xs[(size_t)h * lv.dim + k] = 0.0;
+    for (uint32_t h : c->ad.hact.hang_n[1]) xs[nu + h] = 0.0;
+    CHECK(c->h2d(x, xs.data(), n));
+  } else
   CHECK(c->h2d(x, x_h, n));
   // current_constraints.set_zero(initial guess), local_smoothing.cc:1116
   CHECK(vec_zero_constrained(st, x, lv.cmask_v, lv.n_nodes_v, lv.dim));
@@ -3049,8 +3428,8 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
     CHECK(vec_set(st, x0, 0.0, nu));
     CHECK(c->stokes_residual(tmp, rhs, x0));
     double d2[2];
-    CHECK(c->dots(tmp, {tmp}, c->span_of(0, c->nl() - 1), &d2[0]));
-    CHECK(c->dots(rhs + nu, {rhs + nu}, c->span_of(1, c->nl() - 1), &d2[1]));
+    CHECK(c->dots(tmp, {tmp}, c->span_act(0), &d2[0]));
+    CHECK(c->dots(rhs + nu, {rhs + nu}, c->span_act(1), &d2[1]));
     tol = c->opt.linear_tolerance * std::sqrt(d2[0] + d2[1]);
   } else {  // :1169-1183
     double r0;
@@ -3091,6 +3470,19 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
   for (double v : cc.history) if (rep->n_history < 2048) rep->history[rep->n_history++] = v;
   for (double v : ce.history) if (rep->n_history < 2048) rep->history[rep->n_history++] = v;
   CHECK(c->d2h(x_h, x, n));
+  if (c->ad.on) {   // current_constraints.distribute(solution): hanging nodes take the values of their constraints
+    const HostLevel &hl = c->ad.hact;
+    for (int spc = 0; spc < 2; ++spc) {
+      const int nc = spc == 0 ? lv.dim : 1;
+      const size_t off = spc == 0 ? 0 : nu;
+      for (size_t i = 0; i < hl.hang_n[spc].size(); ++i)
+        for (int k = 0; k < nc; ++k) {
+          double v = 0;
+          for (int q = hl.hang_ptr[spc][i]; q < hl.hang_ptr[spc][i + 1]; ++q) v += hl.hang_w[spc][q] * x_h[off + (size_t)hl.hang_m[spc][q] * nc + k];
+          x_h[off + (size_t)hl.hang_n[spc][i] * nc + k] = v;
+        }
+    }
+  }
   rep->solve_seconds = now_s() - t_setup;
   if (status == 1) set_error("Stokes solver did not converge within the allowed steps");
   return status;
@@ -3099,6 +3491,7 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
 int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *seconds_per_vmult) {
   if (!c || n_repeat < 1 || !seconds_per_vmult) { set_error("bad argument"); return -1; }
   if (c->has_hanging()) { set_error("agmg_bench_vmult: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
+  if (c->ad.on && level == AGMG_ACTIVE) { set_error("agmg_bench_vmult: the active operators of adaptive contexts stage through the host; nothing to time yet"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
@@ -3138,6 +3531,7 @@ int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *se
 int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
   if (!c || !seconds || n_repeat < 1) { set_error("bad argument"); return -1; }
   if (c->has_hanging()) { set_error("agmg_execute_solver_timings: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
+  if (c->ad.on) { set_error("agmg_execute_solver_timings: the active operators of adaptive contexts stage through the host; nothing to time yet"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   {
     CHECK(c->sync());
@@ -3177,7 +3571,7 @@ int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
 
 int agmg_get_level_kernel_path(const agmg_ctx *c, int level, int32_t *n_bricks, int32_t *layers_per_brick, int32_t *n_blocks) {
   if (!c || (level != AGMG_ACTIVE && (level < 0 || level >= (int)c->L.size()))) { set_error("bad level"); return -1; }
-  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->L.back() : c->L[level];
+  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->act() : c->L[level];
   const bool bricks = c->bricks_on(lv);
   if (n_bricks) *n_bricks = bricks ? lv.bk.n_bricks : 0;
   if (layers_per_brick) *layers_per_brick = bricks ? lv.bk.Z : 0;

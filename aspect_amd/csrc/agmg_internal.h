@@ -23,6 +23,7 @@ namespace agmg {
 void set_error(const std::string &msg);
 
 constexpr uint32_t NODE_MASK = 0x1FFFFFFFu;  // low 29 bits: node index; high 3 bits: constraint bits
+constexpr uint32_t NO_CHILD = 0xFFFFFFFFu;   // host side of the transfer tables: the coarse cell is not refined (local smoothing)
 #ifndef AGMG_WAVES_PER_BLOCK
 #define AGMG_WAVES_PER_BLOCK 4
 #endif

@@ -115,8 +115,11 @@ namespace aspect
                     Utilities::MPI::max(h.get_triangulation().n_levels(), h.get_mpi_communicator()),
                     ExcInternalError());
         AssertThrow(!h.get_triangulation().has_hanging_nodes(),
-                    ExcMessage("libaspect_amd.so: uniformly refined meshes only (hanging-node constraints and the "
-                               "edge operators of local smoothing are not in agmg_level_desc yet)"));
+                    ExcMessage("this glue flattens uniformly refined meshes only.  The library takes adaptive ones on one "
+                               "rank (agmg_level_desc: hanging-node CSR from AffineConstraints::get_constraint_entries, "
+                               "refinement_edge_* from mg_constrained_dofs.get_refinement_edge_indices(level), copy_* from "
+                               "the copy_indices of MGLevelGlobalTransfer, agmg_set_level(AGMG_ACTIVE, desc)); flattening "
+                               "them here is the next step of the glue"));
         create(n_levels);
         level_cells.assign(n_levels, {});
         for (unsigned int level = 0; level < n_levels; ++level)

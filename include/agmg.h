@@ -154,11 +154,14 @@ typedef struct agmg_level_desc {
    * hanging_nodes_x[i] takes the value sum_k hanging_weight_x[k] * node hanging_master_x[k],
    * k in [hanging_ptr_x[i], hanging_ptr_x[i+1]); all components of a velocity node share the weights;
    * masters are not hanging themselves.  n_hanging_x == 0 (and NULL tables): none.
-   * FIRST SLICE: accepted on one-level contexts (n_levels == 1: an adaptive active mesh on its own) and
-   * resolved around the operators of the host-vector entry point agmg_vmult; every other entry point
-   * of a context that holds such a level returns status -2.  The edge masks are what the level
-   * operators of local smoothing need (MGConstrainedDoFs::get_refinement_edge_indices, :1804-1813;
-   * vmult_interface_down / _up): carried, not used yet. */
+   * Accepted on the active mesh of an adaptive context (agmg_set_level(AGMG_ACTIVE, desc), below) and on
+   * the level of a one-level, one-rank context.  The edge masks are what the level operators of local
+   * smoothing need (MGConstrainedDoFs::get_refinement_edge_indices, :1804-1813): a level whose mask has a
+   * node set runs its operator with those rows as identity rows (MatrixFreeOperators::Base) and the
+   * interface operators (vmult_interface_down / _up, set_edge_matrices :1045, 1053) in the V-cycle.
+   * FIRST SLICE (one rank): the constraints and the level copies are applied on the host around the
+   * device kernels; agmg_rhs_correction, free-surface faces, agmg_bench_vmult(AGMG_ACTIVE),
+   * agmg_execute_solver_timings and agmg_vmult_device_noalloc return -2 in adaptive contexts. */
   int32_t n_hanging_v, n_hanging_p;
   const uint32_t *hanging_nodes_v; const int32_t *hanging_ptr_v; const uint32_t *hanging_master_v; const double *hanging_weight_v;
   const uint32_t *hanging_nodes_p; const int32_t *hanging_ptr_p; const uint32_t *hanging_master_p; const double *hanging_weight_p;
@@ -263,7 +266,10 @@ int agmg_set_communicator_rccl(agmg_ctx *ctx, const uint8_t id[128]);
 /* setup_dofs(): upload the tables of one level (local_smoothing.cc:1548-1878).
  * level in [0, n_levels) or AGMG_ACTIVE. desc == NULL for AGMG_ACTIVE aliases
  * the active mesh to the finest level (uniformly refined mesh, identical
- * numbering). */
+ * numbering); a descriptor of its own makes the context adaptive: the levels
+ * then hold all cells of their refinement level (set them first, with edge masks
+ * and copy tables), the vectors of vmult / vcycle / precondition / solve are
+ * those of the active mesh. */
 int agmg_set_level(agmg_ctx *ctx, int level, const agmg_level_desc *desc);
 
 /* evaluate_material_model() -> OperatorCellData per level

@@ -1055,3 +1055,56 @@ def test_hanging_node_operators(n_second, per_q, hip_lib, oracle_lib):
         d.free()
     finally:
         g.close(); o.close()
+
+
+@pytest.mark.parametrize("n_second", [0, 5])
+def test_local_smoothing_on_adaptive_meshes(n_second, hip_lib, oracle_lib):
+    """tests/stokes on its second and third mesh through the C-ABI: levels of local smoothing with refinement-edge masks
+    and copy tables, the active mesh with hanging nodes (agmg_set_level(AGMG_ACTIVE, desc)).  Against the oracle: the
+    operators of every level and of the active mesh, inverse diagonals, transfers between partly refined levels,
+    eigenvalue estimates, V-cycles of both blocks, the block preconditioner, and the solve (same iteration count,
+    solution to 1e-8).  (First slice: constraint handling and level copies run on the host around the device kernels.)"""
+    from test_oracle_goldens import _stokes_adaptive_problem
+    p = _stokes_adaptive_problem(n_second)
+    m, H = p.hier.active, p.hier
+    g, o = capi.Solver(hip_lib, p), capi.Solver(oracle_lib, p)
+    try:
+        rng = np.random.Generator(np.random.PCG64(17))
+        for l, lev in enumerate(H.levels):
+            for which, n in ((capi.OP_A, lev.n_dofs_v), (capi.OP_MASS, lev.n_dofs_p)):
+                src = rng.uniform(-1, 1, n)
+                assert relerr(g.vmult(which, src, level=l), o.vmult(which, src, level=l)) < RTOL, (l, which)
+                assert relerr(g.inverse_diagonal(which, l), o.inverse_diagonal(which, l)) < RTOL, (l, which)
+            if l > 0:
+                for which, nf, ncz in ((capi.OP_A, lev.n_dofs_v, H.levels[l - 1].n_dofs_v), (capi.OP_MASS, lev.n_dofs_p, H.levels[l - 1].n_dofs_p)):
+                    f, cz = rng.uniform(-1, 1, nf), rng.uniform(-1, 1, ncz)
+                    assert relerr(g.prolongate_add(which, l, f, cz), o.prolongate_add(which, l, f, cz)) < RTOL, (l, which)
+                    assert relerr(g.restrict_add(which, l, cz, f), o.restrict_add(which, l, cz, f)) < RTOL, (l, which)
+        for which in (capi.OP_A, capi.OP_STOKES, capi.OP_BT, capi.OP_MASS):
+            src = rng.uniform(-1, 1, g.size(which))
+            assert relerr(g.vmult(which, src), o.vmult(which, src)) < RTOL, which
+        g.setup_smoothers(); o.setup_smoothers()
+        for l in range(H.n_levels):
+            for which in (capi.OP_A, capi.OP_MASS):
+                a, b = g.eigenvalue_estimates(which, l), o.eigenvalue_estimates(which, l)
+                # (27 pressure nodes on level 1: ten CG steps exhaust the Krylov space of the start vector, the last
+                # Lanczos coefficients are rounding and the two estimates of 1.2 * 1.5^3 = 4.05 agree to 1e-5 only)
+                tol = 1e-4 if (which == capi.OP_MASS and H.levels[l].n_nodes_p <= 27) else 1e-8
+                assert abs(a[1] / b[1] - 1.0) < tol and abs(a[0] / b[0] - 1.0) < tol, (l, which, a, b)
+        free_u = ~(m.constrained_dofs_v() | m.hanging_dofs_v())
+        free_p = ~np.isin(np.arange(m.n_nodes_p), m.hanging_p[0])
+        for which, fr in ((capi.OP_A, free_u), (capi.OP_MASS, free_p)):
+            src = rng.uniform(-1, 1, fr.size) * fr
+            a, b = g.vcycle(which, src), o.vcycle(which, src)
+            assert relerr(a, b) < (1e-12 if which == capi.OP_A else 1e-8), which        # (mass: the level-1 estimates above)
+            assert np.abs(a[~fr]).max() == 0.0
+        src = np.concatenate([rng.uniform(-1, 1, free_u.size) * free_u, rng.uniform(-1, 1, free_p.size) * free_p])
+        assert relerr(g.precondition(src), o.precondition(src)) < 1e-9
+        xg, rg, _ = g.solve()
+        xo, ro, _ = o.solve()
+        assert rg.n_cheap_iterations == ro.n_cheap_iterations and rg.n_expensive_iterations == 0
+        nu = m.n_dofs_v
+        assert relerr(xg[:nu], xo[:nu]) < 1e-9 and relerr(xg[nu:], xo[nu:]) < 1e-9
+        assert np.abs(m.distribute_v(xg[:nu]) - xg[:nu]).max() <= 1e-12 * np.abs(xg[:nu]).max()
+    finally:
+        g.close(); o.close()
