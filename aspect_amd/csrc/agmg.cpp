@@ -163,11 +163,12 @@ struct agmg_ctx {
     std::vector<HostLevel> Hb;
     std::vector<uint8_t *> edge[2], notedge[2];        // [velocity | pressure][level] device masks, nullptr without an edge
     std::vector<std::vector<uint32_t>> copy_act[2], copy_lev[2];   // [velocity | pressure][level] MGLevelGlobalTransfer::copy_indices
+    std::vector<uint32_t *> copy_act_d[2], copy_lev_d[2];          // the same tables on the device
+    HangTables hang[2];                                            // hanging-node CSRs of the active mesh on the device
     // pull tables of level l - 1 that leave out the cells without children (restriction from level l), [space][l]
     std::vector<uint32_t *> rpull_ptr[2], rpull_list[2];
     double *xres = nullptr;      // a source vector with its hanging entries resolved [n_u + n_p]
     size_t xres_cap = 0;
-    std::vector<double> hx, hy;  // host staging of the constraint handling and of the level copies
   } ad;
   bool has_edge(int l) const { return ad.on && l >= 0 && l < (int)ad.Lb.size() && ad.Lb[l].set; }
   void free_adaptive_level(int l);
@@ -1106,13 +1107,11 @@ int agmg_ctx::apply_on(const DeviceLevel &lv, int which01, const CoeffData &cd, 
 // Operators of the active mesh of an adaptive context.  MatrixFree resolves the hanging-node constraints when it reads
 // cell values and applies their transpose when it writes (read_dof_values / distribute_local_to_global); constrained
 // rows are identity rows: y = C^T A C x around the device operators, which treat every node as its own DoF.
-// FIRST SLICE: C and C^T are applied on the host (the vector crosses PCIe twice per application); the cell work, the
-// smoothers and the transfers run in the device kernels of the uniform path.  Device-side gather kernels for the two
-// CSRs are the next step.
+// C and C^T are index kernels over the constraint CSR and its transpose (vec_hang_resolve / _distribute / _restore); the
+// vector never leaves the device.
 // src: [u], [p] or [u; p] as `which` asks; b != NULL: dst = b - op(src).
 int agmg_ctx::active_apply(int which, double *dst, const double *src, const double *b) {
   const DeviceLevel &lv = ad.act;
-  const HostLevel &hl = ad.hact;
   const CoeffData &cd = active_coeff();
   const int dim = lv.dim;
   const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p();
@@ -1120,37 +1119,9 @@ int agmg_ctx::active_apply(int which, double *dst, const double *src, const doub
   const size_t poff = has_u ? nu : 0, n = (has_u ? nu : 0) + (has_p ? np : 0);
   if (ad.xres_cap < nu + np) { dfree(ad.xres); CHECK(dalloc(&ad.xres, nu + np)); ad.xres_cap = nu + np; }
   double *xr = ad.xres;
-  std::vector<double> &hx = ad.hx, &hy = ad.hy;
-  hx.resize(n); hy.resize(n);
-  auto con = [&](int sp, uint32_t node, int comp) { return sp == 0 ? ((hl.cmask[0][node] >> comp) & 1) != 0 : (hl.cmask[1][node] & 1) != 0; };
-  CHECK(d2h(hx.data(), src, n));
-  std::vector<double> src_h[2];   // the entries of the hanging nodes as they came in (identity rows)
-  auto resolve = [&](int sp, size_t off, int nc) {
-    src_h[sp].resize(hl.hang_n[sp].size() * nc);
-    for (size_t i = 0; i < hl.hang_n[sp].size(); ++i)
-      for (int comp = 0; comp < nc; ++comp) {
-        double v = 0;
-        for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k)
-          if (!con(sp, hl.hang_m[sp][k], comp)) v += hl.hang_w[sp][k] * hx[off + (size_t)hl.hang_m[sp][k] * nc + comp];
-        double &slot = hx[off + (size_t)hl.hang_n[sp][i] * nc + comp];
-        src_h[sp][i * nc + comp] = slot;
-        slot = v;
-      }
-  };
-  auto distribute = [&](int sp, size_t off, int nc) {
-    for (size_t i = 0; i < hl.hang_n[sp].size(); ++i) {
-      const uint32_t h = hl.hang_n[sp][i];
-      for (int comp = 0; comp < nc; ++comp) {
-        if (!con(sp, h, comp))
-          for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k)
-            if (!con(sp, hl.hang_m[sp][k], comp)) hy[off + (size_t)hl.hang_m[sp][k] * nc + comp] += hl.hang_w[sp][k] * hy[off + (size_t)h * nc + comp];
-        hy[off + (size_t)h * nc + comp] = src_h[sp][i * nc + comp];
-      }
-    }
-  };
-  if (has_u) resolve(0, 0, dim);
-  if (has_p) resolve(1, poff, 1);
-  CHECK(h2d(xr, hx.data(), n));
+  CHECK(vec_copy(stream, xr, src, n));
+  if (has_u) CHECK(vec_hang_resolve(stream, xr, ad.hang[0], lv.cmask_v, dim));
+  if (has_p) CHECK(vec_hang_resolve(stream, xr + poff, ad.hang[1], lv.cmask_p, 1));
   EpiArgs e;
   e.epi = EPI_STORE; e.dst = dst; e.x = xr;
   switch (which) {
@@ -1169,10 +1140,14 @@ int agmg_ctx::active_apply(int which, double *dst, const double *src, const doub
       CHECK(op_velocity(lv, cd, AGMG_OP_BT, nullptr, xr + nu, e));
       CHECK(vec_set(stream, dst + nu, 0.0, np));
   }
-  CHECK(d2h(hy.data(), dst, n));
-  if (has_u) distribute(0, 0, dim);
-  if (which == AGMG_OP_MASS || which == AGMG_OP_STOKES) distribute(1, poff, 1);   // (B^T writes no pressure rows)
-  CHECK(h2d(dst, hy.data(), n));
+  if (has_u) {
+    CHECK(vec_hang_distribute(stream, dst, ad.hang[0], lv.cmask_v, dim));
+    CHECK(vec_hang_restore(stream, dst, ad.hang[0], dim));
+  }
+  if (which == AGMG_OP_MASS || which == AGMG_OP_STOKES) {   // (B^T writes no pressure rows)
+    CHECK(vec_hang_distribute(stream, dst + poff, ad.hang[1], lv.cmask_p, 1));
+    CHECK(vec_hang_restore(stream, dst + poff, ad.hang[1], 1));
+  }
   if (b) CHECK(vec_lincomb(stream, dst, 1.0, b, -1.0, dst, n));
   return 0;
 }
@@ -1549,33 +1524,20 @@ int agmg_ctx::interface_up_into_defect(int which, int l) {
 
 // PreconditionMG::vmult of an adaptive context: copy_to_mg fills the defect of EVERY level through its copy table (the
 // cells that are active on the level), the cycle runs from the finest level, copy_from_mg gathers the solutions.
-// FIRST SLICE: the two copies are host loops over the tables (see active_apply).
 int agmg_ctx::vcycle_adaptive(int which, double *dst, const double *src) {
   const int top = nl() - 1, nc = which == 0 ? opt.dim : 1;
   const size_t n = which == 0 ? (size_t)ad.act.n_dofs_v() : (size_t)ad.act.n_dofs_p();
-  std::vector<double> &hx = ad.hx, &hy = ad.hy;
-  hx.resize(n);
-  CHECK(d2h(hx.data(), src, n));
   for (int l = 0; l <= top; ++l) {
-    const size_t nl_ = size_of(which, l);
-    hy.assign(nl_, 0.0);
-    const std::vector<uint32_t> &ca = ad.copy_act[which][l], &cl = ad.copy_lev[which][l];
-    for (size_t i = 0; i < ca.size(); ++i)
-      for (int c = 0; c < nc; ++c) hy[(size_t)cl[i] * nc + c] = hx[(size_t)ca[i] * nc + c];
-    CHECK(h2d(mg_def[which][l], hy.data(), nl_));
+    CHECK(vec_set(stream, mg_def[which][l], 0.0, size_of(which, l)));
+    CHECK(vec_copy_nodes(stream, mg_def[which][l], ad.copy_lev_d[which][l], src, ad.copy_act_d[which][l],
+                         (int)ad.copy_act[which][l].size(), nc));
   }
   CHECK(level_v_step(which, top));
-  hx.assign(n, 0.0);
-  for (int l = 0; l <= top; ++l) {
-    const std::vector<uint32_t> &ca = ad.copy_act[which][l], &cl = ad.copy_lev[which][l];
-    if (ca.empty()) continue;
-    const size_t nl_ = size_of(which, l);
-    hy.resize(nl_);
-    CHECK(d2h(hy.data(), mg_sol[which][l], nl_));
-    for (size_t i = 0; i < ca.size(); ++i)
-      for (int c = 0; c < nc; ++c) hx[(size_t)ca[i] * nc + c] = hy[(size_t)cl[i] * nc + c];
-  }
-  return h2d(dst, hx.data(), n);
+  CHECK(vec_set(stream, dst, 0.0, n));
+  for (int l = 0; l <= top; ++l)
+    CHECK(vec_copy_nodes(stream, dst, ad.copy_act_d[which][l], mg_sol[which][l], ad.copy_lev_d[which][l],
+                         (int)ad.copy_act[which][l].size(), nc));
+  return 0;
 }
 
 // PreconditionMG::vmult on device vectors of the active (= finest) mesh
@@ -2677,7 +2639,7 @@ void agmg_ctx::free_adaptive_level(int l) {
   if (l < (int)ad.Lb.size()) { free_level(ad.Lb[l]); ad.Hb[l] = HostLevel(); }
   for (int w = 0; w < 2; ++w) {
     if (l < (int)ad.edge[w].size()) { dfree(ad.edge[w][l]); dfree(ad.notedge[w][l]); }
-    if (l < (int)ad.copy_act[w].size()) { ad.copy_act[w][l].clear(); ad.copy_lev[w][l].clear(); }
+    if (l < (int)ad.copy_act[w].size()) { ad.copy_act[w][l].clear(); ad.copy_lev[w][l].clear(); dfree(ad.copy_act_d[w][l]); dfree(ad.copy_lev_d[w][l]); }
     for (int k = l; k <= l + 1; ++k)   // restriction tables that involve this level as the fine or the coarse one
       if (k < (int)ad.rpull_ptr[w].size()) { dfree(ad.rpull_ptr[w][k]); dfree(ad.rpull_list[w][k]); }
   }
@@ -2687,6 +2649,10 @@ void agmg_ctx::free_adaptive_active() {
   ad.hact = HostLevel();
   dfree(ad.xres);
   ad.xres_cap = 0;
+  for (HangTables &t : ad.hang) {
+    dfree(t.hn); dfree(t.hm); dfree(t.tm); dfree(t.th); dfree(t.hptr); dfree(t.tptr); dfree(t.hw); dfree(t.tw); dfree(t.saved);
+    t = HangTables();
+  }
   ad.on = false;
 }
 
@@ -2787,6 +2753,7 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
       for (int w = 0; w < 2; ++w) {
         ad.edge[w].assign(nl, nullptr); ad.notedge[w].assign(nl, nullptr);
         ad.copy_act[w].assign(nl, {}); ad.copy_lev[w].assign(nl, {});
+        ad.copy_act_d[w].assign(nl, nullptr); ad.copy_lev_d[w].assign(nl, nullptr);
         ad.rpull_ptr[w].assign(nl, nullptr); ad.rpull_list[w].assign(nl, nullptr);
       }
     }
@@ -2808,12 +2775,38 @@ int agmg_set_level(agmg_ctx *c, int level, const agmg_level_desc *d) {
       const uint32_t *ca = w == 0 ? d->copy_active_v : d->copy_active_p, *cl = w == 0 ? d->copy_level_v : d->copy_level_p;
       ad.copy_act[w][level].assign(ca, ca + nc);
       ad.copy_lev[w][level].assign(cl, cl + nc);
+      CHECK(c->upload(&ad.copy_act_d[w][level], ad.copy_act[w][level]));
+      CHECK(c->upload(&ad.copy_lev_d[w][level], ad.copy_lev[w][level]));
     }
     if (level + 1 < nl) c->L[level + 1].has_transfer = false;
     lv.has_transfer = false;
   } else {
-    // (the hanging-node CSRs stay on the host, in ad.hact: first slice, see active_apply)
+    // the hanging-node CSRs and their transposes (master -> hanging nodes, terms in the order of the table) on the device
     agmg_ctx::Adaptive &ad = c->ad;
+    for (int sp = 0; sp < 2; ++sp) {
+      HangTables &t = ad.hang[sp];
+      const int nh = (int)hl.hang_n[sp].size(), nn = sp == 0 ? d->n_nodes_v : d->n_nodes_p;
+      t.n_hang = nh;
+      std::vector<int32_t> slot(nn, -1), tptr(1, 0);
+      std::vector<uint32_t> tm;
+      for (uint32_t m : hl.hang_m[sp]) if (slot[m] < 0) { slot[m] = (int32_t)tm.size(); tm.push_back(m); tptr.push_back(0); }
+      for (uint32_t m : hl.hang_m[sp]) ++tptr[slot[m] + 1];
+      for (size_t k = 1; k < tptr.size(); ++k) tptr[k] += tptr[k - 1];
+      std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+      std::vector<uint32_t> th(hl.hang_m[sp].size());
+      std::vector<double> tw(hl.hang_m[sp].size());
+      for (int i = 0; i < nh; ++i)
+        for (int k = hl.hang_ptr[sp][i]; k < hl.hang_ptr[sp][i + 1]; ++k) {
+          const int at = fill[slot[hl.hang_m[sp][k]]]++;
+          th[at] = hl.hang_n[sp][i]; tw[at] = hl.hang_w[sp][k];
+        }
+      t.n_masters = (int)tm.size();
+      if (hl.hang_ptr[sp].empty()) hl.hang_ptr[sp].assign(1, 0);
+      CHECK(c->upload(&t.hn, hl.hang_n[sp])); CHECK(c->upload(&t.hptr, hl.hang_ptr[sp]));
+      CHECK(c->upload(&t.hm, hl.hang_m[sp])); CHECK(c->upload(&t.hw, hl.hang_w[sp]));
+      CHECK(c->upload(&t.tm, tm)); CHECK(c->upload(&t.tptr, tptr)); CHECK(c->upload(&t.th, th)); CHECK(c->upload(&t.tw, tw));
+      CHECK(c->dalloc(&t.saved, (size_t)nh * (sp == 0 ? dim : 1)));
+    }
     ad.on = true;
   }
   c->mg_alloc = false; c->diag_ready = false; c->smoothers_ready = false;

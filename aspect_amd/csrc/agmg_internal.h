@@ -332,6 +332,20 @@ int vec_fill_gid_mod(hipStream_t s, double *x, const uint32_t *gid, int n_nodes,
 // out[k*nc + c] = x[nodes[k]*nc + c]
 int vec_gather_nodes(hipStream_t s, double *out, const double *x, const uint32_t *nodes, int n, int nc);
 int vec_shift(hipStream_t s, double *x, double a, size_t n);  // x += a
+// hanging-node constraints of one node space on the device: the CSR hanging node -> (master, weight) as the caller
+// gave it, its transpose master -> (hanging node, weight) in the same order of terms, and room for the entries of the
+// hanging nodes as they came in (identity rows)
+struct HangTables {
+  int n_hang = 0, n_masters = 0;
+  uint32_t *hn = nullptr, *hm = nullptr, *tm = nullptr, *th = nullptr;
+  int32_t *hptr = nullptr, *tptr = nullptr;
+  double *hw = nullptr, *tw = nullptr, *saved = nullptr;
+};
+int vec_hang_resolve(hipStream_t s, double *x, const HangTables &t, const uint8_t *cmask, int nc);
+int vec_hang_distribute(hipStream_t s, double *y, const HangTables &t, const uint8_t *cmask, int nc);
+int vec_hang_restore(hipStream_t s, double *y, const HangTables &t, int nc);
+// dst[dst_nodes[k]*nc + c] = src[src_nodes[k]*nc + c]
+int vec_copy_nodes(hipStream_t s, double *dst, const uint32_t *dst_nodes, const double *src, const uint32_t *src_nodes, int n_nodes, int nc);
 constexpr int DOT_BLOCKS = 256;
 constexpr int DOT_MAX_VECS = 8;
 // out[k] = <x, ys[k]> for k < nvec <= DOT_MAX_VECS; result on device in `out`

@@ -112,6 +112,57 @@ __global__ void __launch_bounds__(VB) k_gather_nodes(double *out, const double *
   }
 }
 
+
+// ---- hanging-node constraints of the active mesh of an adaptive context (MatrixFree's read_dof_values /
+// distribute_local_to_global around the cell loop) and the level copies of MGLevelGlobalTransfer, as index kernels.
+// Masters are never hanging themselves (checked at agmg_set_level), so readers and writers never meet.
+// x[h] <- sum_k w_k x[m_k] over the unconstrained masters; the entry as it came in is kept in `saved`
+__global__ void __launch_bounds__(VB) k_hang_resolve(double *x, const uint32_t *hn, const int32_t *hptr, const uint32_t *hm,
+                                                     const double *hw, const uint8_t *cmask, size_t n, int nc, double *saved) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t k = i / nc;
+    const int c = (int)(i - k * nc);
+    double v = 0.0;
+    for (int q = hptr[k]; q < hptr[k + 1]; ++q) {
+      const uint32_t m = hm[q];
+      if (!((cmask[m] >> c) & 1u)) v += hw[q] * x[(size_t)m * nc + c];
+    }
+    const size_t at = (size_t)hn[k] * nc + c;
+    saved[i] = x[at];
+    x[at] = v;
+  }
+}
+// transpose, one thread per (master, component), the hanging nodes of a master in the order of the constraint table:
+// y[m] += sum w y[h] over its unconstrained hanging nodes
+__global__ void __launch_bounds__(VB) k_hang_distribute(double *y, const uint32_t *tm, const int32_t *tptr, const uint32_t *th,
+                                                        const double *tw, const uint8_t *cmask, size_t n, int nc) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t k = i / nc;
+    const int c = (int)(i - k * nc);
+    const uint32_t m = tm[k];
+    if ((cmask[m] >> c) & 1u) continue;
+    double v = y[(size_t)m * nc + c];
+    for (int q = tptr[k]; q < tptr[k + 1]; ++q) {
+      const uint32_t h = th[q];
+      if (!((cmask[h] >> c) & 1u)) v += tw[q] * y[(size_t)h * nc + c];
+    }
+    y[(size_t)m * nc + c] = v;
+  }
+}
+// identity rows of the hanging nodes
+__global__ void __launch_bounds__(VB) k_hang_restore(double *y, const uint32_t *hn, const double *saved, size_t n, int nc) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t k = i / nc;
+    y[(size_t)hn[k] * nc + (i - k * nc)] = saved[i];
+  }
+}
+__global__ void __launch_bounds__(VB) k_copy_nodes(double *dst, const uint32_t *dn, const double *src, const uint32_t *sn, size_t n, int nc) {
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
+    const size_t k = i / nc, c = i - k * nc;
+    dst[(size_t)dn[k] * nc + c] = src[(size_t)sn[k] * nc + c];
+  }
+}
+
 template <int NV>
 __global__ void __launch_bounds__(VB) k_multi_axpy(double *y, VecPtrs xs, Coeffs a, size_t n) {
   for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += (size_t)gridDim.x * VB) {
@@ -200,6 +251,23 @@ int vec_fill_gid_mod(hipStream_t s, double *x, const uint32_t *gid, int n_nodes,
 int vec_gather_nodes(hipStream_t s, double *out, const double *x, const uint32_t *nodes, int n_nodes, int nc) {
   const size_t n = (size_t)n_nodes * nc;
   LAUNCH_VEC(k_gather_nodes, n, out, x, nodes, n, nc);
+}
+
+int vec_hang_resolve(hipStream_t s, double *x, const HangTables &t, const uint8_t *cmask, int nc) {
+  const size_t n = (size_t)t.n_hang * nc;
+  LAUNCH_VEC(k_hang_resolve, n, x, t.hn, t.hptr, t.hm, t.hw, cmask, n, nc, t.saved);
+}
+int vec_hang_distribute(hipStream_t s, double *y, const HangTables &t, const uint8_t *cmask, int nc) {
+  const size_t n = (size_t)t.n_masters * nc;
+  LAUNCH_VEC(k_hang_distribute, n, y, t.tm, t.tptr, t.th, t.tw, cmask, n, nc);
+}
+int vec_hang_restore(hipStream_t s, double *y, const HangTables &t, int nc) {
+  const size_t n = (size_t)t.n_hang * nc;
+  LAUNCH_VEC(k_hang_restore, n, y, t.hn, t.saved, n, nc);
+}
+int vec_copy_nodes(hipStream_t s, double *dst, const uint32_t *dst_nodes, const double *src, const uint32_t *src_nodes, int n_nodes, int nc) {
+  const size_t n = (size_t)n_nodes * nc;
+  LAUNCH_VEC(k_copy_nodes, n, dst, dst_nodes, src, src_nodes, n, nc);
 }
 
 int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, size_t n, size_t seg1, size_t gap,
