@@ -363,9 +363,14 @@ def _dgq1_restriction(dim):
     return np.stack(out)
 
 
-def viscosity_tables(hier, eta_func, averaging, eta_q=None):
+def viscosity_tables(hier, eta_func, averaging, eta_q=None, gather=None, n_replicated=0):
     """Return (active_table, [level tables], eta_min, eta_max).  eta_q: the viscosity at the q-points of the finest
     level [n_cells][3^dim] in place of eta_func (solution-dependent rheologies).
+
+    Rank-local hierarchies whose levels 0..n_replicated-1 are held whole by every rank (partition.RankLocalHierarchy):
+    `gather(array)` returns the arrays of all ranks concatenated in rank order (= global cell order, a rank's cells
+    being a contiguous run of it); it is called once, on the cell values of the coarsest distributed level, before
+    they are coarsened onto the replicated levels, and once on the extreme values.
 
     Tables are ``[n_cells][1]`` (DGQ0) or ``[n_cells][3^dim]`` (per q-point)
     exactly as OperatorCellData::viscosity's second extent
@@ -391,6 +396,8 @@ def viscosity_tables(hier, eta_func, averaging, eta_q=None):
         cur = cellv
         levels[nL - 1] = cur[:, None].copy()
         for l in range(nL - 2, -1, -1):
+            if gather is not None and l == n_replicated - 1:
+                cur = gather(cur)
             # FE_DGQ(0) restriction: arithmetic mean of the children
             cur = cur.reshape(-1, ch).mean(axis=1)
             levels[l] = cur[:, None].copy()
@@ -407,6 +414,8 @@ def viscosity_tables(hier, eta_func, averaging, eta_q=None):
         levels = [None] * nL
         levels[nL - 1] = cur[:, None].copy()
         for l in range(nL - 2, -1, -1):
+            if gather is not None and l == n_replicated - 1:
+                cur = gather(cur)
             cur = cur.reshape(-1, ch).mean(axis=1)
             levels[l] = cur[:, None].copy()
         return eta_q.copy(), levels, eta_min, eta_max
@@ -422,8 +431,14 @@ def viscosity_tables(hier, eta_func, averaging, eta_q=None):
         R = _dgq1_restriction(dim)
         levels = [None] * nL
         cur = nodal
+        if gather is not None and n_replicated > 0:
+            # (the level tables are clamped to the extreme values of the whole mesh, local_smoothing.cc:432-437)
+            ext = gather(np.array([eta_min, -eta_max]))
+            eta_min, eta_max = float(ext[0::2].min()), float(-ext[1::2].min())
         for l in range(nL - 1, -1, -1):
             if l < nL - 1:
+                if gather is not None and l == n_replicated - 1:
+                    cur = gather(cur)
                 child = cur.reshape(-1, ch, ch)        # [parent][child][j]
                 cur = np.einsum("cij,pcj->pi", R, child)
             levels[l] = np.clip(cur @ Nq.T, eta_min, eta_max)

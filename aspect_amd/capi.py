@@ -60,6 +60,7 @@ class LevelDesc(C.Structure):
         ("refinement_edge_v", c_u8p), ("refinement_edge_p", c_u8p),
         ("n_copy_v", C.c_int32), ("n_copy_p", C.c_int32),
         ("copy_active_v", c_u32p), ("copy_level_v", c_u32p), ("copy_active_p", c_u32p), ("copy_level_p", c_u32p),
+        ("replicated", C.c_int32),
     ]
 
 
@@ -279,7 +280,9 @@ class Solver:
         else:
             d.geometry_kind = GEOM_CARTESIAN
             d.cell_h = _ptr(ch, C.c_double)
-        if getattr(lev, "neighbors", None) is not None and self.transport is not None:
+        # a level every rank holds whole (distributed contexts; agmg_level_desc::replicated): no exchange plan
+        d.replicated = int(bool(getattr(lev, "replicated", False)) and self.transport is not None)
+        if getattr(lev, "neighbors", None) is not None and self.transport is not None and not d.replicated:
             d.n_owned_nodes_v, d.n_owned_nodes_p = lev.n_owned_nodes_v, lev.n_owned_nodes_p
             nb = np.ascontiguousarray(lev.neighbors, dtype=np.int32)
             plan = [np.ascontiguousarray(a) for a in (lev.send_offsets_v, lev.send_nodes_v, lev.recv_offsets_v,

@@ -227,6 +227,11 @@ struct agmg_ctx {
   size_t stage_cap = 0;
   // (a 1-rank context with a bound transport runs the distributed code paths too: tests)
   bool dist() const { return opt.world_size > 1 || comm_set; }
+  // a level of a distributed context that is really partitioned (a replicated level, agmg_level_desc::replicated, is held
+  // whole by every rank and runs the one-rank code paths)
+  bool ldist(const DeviceLevel &lv) const { return dist() && !lv.replicated; }
+  // in-place sum over ranks of a device vector (the restriction onto the last replicated level)
+  int allreduce_vec(double *d, size_t n);
   struct Msg { int peer; const double *send; int64_t n_send; double *recv; int64_t n_recv; };
   int exchange(const std::vector<Msg> &msgs);
   // owner -> ghost copies of `vec` (nc values per node, nc <= x.nc)
@@ -275,11 +280,12 @@ struct agmg_ctx {
   int allreduce_host(double *v, int n);
   // A vector of the solve: n local entries (owned + ghost); dot products run over the owned
   // entries only: logical entry i < n_dot lives at i (i < seg1) or at i + gap
-  struct Span { size_t n, n_dot, seg1, gap; };
+  // local: the vector lives on a replicated level, every rank holds all of it and computes the same sums (no all-reduce)
+  struct Span { size_t n, n_dot, seg1, gap; bool local = false; };
   Span span_of(int which, int l) const {
     const DeviceLevel &lv = L[l];
-    if (which == 0) { const size_t o = (size_t)lv.n_owned_v * lv.dim; return {(size_t)lv.n_dofs_v(), o, o, 0}; }
-    return {(size_t)lv.n_dofs_p(), (size_t)lv.n_owned_p, (size_t)lv.n_owned_p, 0};
+    if (which == 0) { const size_t o = (size_t)lv.n_owned_v * lv.dim; return {(size_t)lv.n_dofs_v(), o, o, 0, lv.replicated}; }
+    return {(size_t)lv.n_dofs_p(), (size_t)lv.n_owned_p, (size_t)lv.n_owned_p, 0, lv.replicated};
   }
   Span span_up() const {
     const DeviceLevel &lv = ad.on ? ad.act : L.back();
@@ -292,7 +298,7 @@ struct agmg_ctx {
   // per tree of a box is 81 + 8 DoFs; the 96-cell shell (2910 + 150) would spend the V-cycle in a
   // 2910^2 host matvec, so larger coarse levels run the same smoother on the device
   static constexpr size_t COARSE_HOST_MAX_DOFS = 600;
-  bool coarse_host(int which) const { return opt.coarse_on_host && !dist() && size_of(which, 0) <= COARSE_HOST_MAX_DOFS; }
+  bool coarse_host(int which) const { return opt.coarse_on_host && !L.empty() && !ldist(L[0]) && size_of(which, 0) <= COARSE_HOST_MAX_DOFS; }
   DeviceLevel &fin() { return L.back(); }
   // the active mesh: the finest level (uniform refinement) or the tables set with agmg_set_level(AGMG_ACTIVE, desc)
   DeviceLevel &act() { return ad.on ? ad.act : L.back(); }
@@ -337,7 +343,7 @@ struct agmg_ctx {
   bool use_blocks = true;
   bool use_ell = true;     // assembled rows for the Q1 mass operator (AGMG_NO_ELL=1: matrix-free cell kernel + pull)
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
-    return use_ell && !dist() && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
+    return use_ell && !ldist(lv) && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
   }
   bool use_batched_setup = true;   // eigenvalue estimates of all levels in lock step (AGMG_NO_BATCHED_SETUP=1: one by one)
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
@@ -346,7 +352,7 @@ struct agmg_ctx {
   void program_step(const Smoother &s, SmootherProgram &p) const;
   bool fused_mass(int l) const { return use_fused && L[l].mass_fusable; }
   // A block on a level that is one workgroup: the Chebyshev sequence (and the residual behind it) in one launch
-  bool fused_A(int l) const { return use_fused && use_blocks && !dist() && blk_seq_possible(L[l], L[l].coeff); }
+  bool fused_A(int l) const { return use_fused && use_blocks && !ldist(L[l]) && blk_seq_possible(L[l], L[l].coeff); }
   int smooth_A_seq(int l, bool zero_start, const double *rhs, double *resid_dst);
   void free_level(DeviceLevel &l);
   void free_coeff(CoeffData &cd) {
@@ -364,7 +370,7 @@ struct agmg_ctx {
   int use_bricks = 2;       // 0 off, 1 every level that qualifies, 2 large levels only
   int brick_z_override = 0; // AGMG_BRICK_Z: layers per brick (1, 2, 4 or 8) instead of the size-based choice
   int brick_stack_override = 0; // AGMG_BRICK_STACK: cubes per brick along z (1, 2 or 4) instead of the size-based choice
-  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && !dist(); }
+  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && !ldist(lv); }
   int ensure_workspace();
   int ensure_transfers();
   int ensure_mg_vectors();
@@ -612,7 +618,7 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
 int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv) {
   BrickTables &bk = lv.bk;
   const int n = lv.n_cells, nn = lv.n_nodes_v;
-  if (lv.dim != 3 || n < 512 || n % 512 != 0 || (unsigned)nn > BRICK_NODE_MASK || dist()) return 0;
+  if (lv.dim != 3 || n < 512 || n % 512 != 0 || (unsigned)nn > BRICK_NODE_MASK || ldist(lv)) return 0;
   if (lv.geom != AGMG_GEOM_CARTESIAN) return 0;                 // (the brick kernel reads cell extents)
   if (use_bricks == 2 && n < 512 * 512) return 0;               // small levels: the block kernels are faster
   const uint32_t *cnv = hl.cnv.data();
@@ -854,20 +860,21 @@ int agmg_ctx::get_vec(size_t idx, double **p) {
 int agmg_ctx::dots(const double *x, const std::vector<const double *> &ys, const Span &sp, double *out) {
   const int total = (int)ys.size();
   if (total > 256) { set_error("dots: too many vectors"); return -1; }
+  const bool red = dist() && !sp.local;   // (a replicated level: every rank computes the whole sum itself)
   for (int k0 = 0; k0 < total; k0 += DOT_MAX_VECS) {
     const int nv = std::min(DOT_MAX_VECS, total - k0);
     VecPtrs vp;
     for (int k = 0; k < DOT_MAX_VECS; ++k) vp.p[k] = ys[k0 + std::min(k, nv - 1)];
     // one rank: the final reduction writes straight into the pinned (device-visible, coherent) host
     // buffer: no copy kernel between the reduction and the host's wait
-    CHECK(vec_multi_dot(stream, x, vp, nv, sp.n_dot, sp.seg1, sp.gap, dot_partials, (dist() ? dot_out_d : dot_out_h) + k0));
+    CHECK(vec_multi_dot(stream, x, vp, nv, sp.n_dot, sp.seg1, sp.gap, dot_partials, (red ? dot_out_d : dot_out_h) + k0));
   }
-  if (dist() && comm.device_buffers) {
+  if (red && comm.device_buffers) {
     if (comm.allreduce_sum(comm.user, dot_out_d, total, (void *)stream)) { set_error("all-reduce callback failed"); return -101; }
   }
-  if (dist()) AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+  if (red) AGMG_HIP_CHECK(hipMemcpyAsync(dot_out_h, dot_out_d, total * sizeof(double), hipMemcpyDeviceToHost, stream));
   CHECK(sync());
-  if (dist() && !comm.device_buffers) {
+  if (red && !comm.device_buffers) {
     if (comm.allreduce_sum(comm.user, dot_out_h, total, nullptr)) { set_error("all-reduce callback failed"); return -101; }
   }
   for (int k = 0; k < total; ++k) out[k] = dot_out_h[k];
@@ -889,6 +896,25 @@ int agmg_ctx::allreduce_host(double *v, int n) {
   CHECK(sync());
   for (int k = 0; k < n; ++k) v[k] = dot_out_h[k];
   return 0;
+}
+
+int agmg_ctx::allreduce_vec(double *d, size_t n) {
+  if (!dist() || n == 0) return 0;
+  if (!comm_set) { set_error("distributed context without a communicator (agmg_set_communicator)"); return -1; }
+  if (n > 0x7FFFFFFFull) { set_error("allreduce_vec: vector too long"); return -1; }
+  if (comm.device_buffers) {
+    if (comm.allreduce_sum(comm.user, d, (int32_t)n, (void *)stream)) { set_error("all-reduce callback failed"); return -101; }
+    return 0;
+  }
+  if (n > stage_cap) {
+    if (stage_h) (void)hipHostFree(stage_h);
+    stage_h = nullptr; stage_cap = 0;
+    AGMG_HIP_CHECK(hipHostMalloc((void **)&stage_h, (n + n / 2 + 64) * sizeof(double)));
+    stage_cap = n + n / 2 + 64;
+  }
+  CHECK(d2h(stage_h, d, n));
+  if (comm.allreduce_sum(comm.user, stage_h, (int32_t)n, nullptr)) { set_error("all-reduce callback failed"); return -101; }
+  return h2d(d, stage_h, n);
 }
 
 // ===================================================================== ghost exchange
@@ -980,6 +1006,10 @@ int agmg_ctx::ensure_transfers() {
     const HostLevel &HF = H[l];
     if (HF.parent.empty()) { set_error("level " + std::to_string(l) + " has no parent_cell/child_index table"); return -1; }
     const DeviceLevel &C = L[l - 1];
+    // the first distributed level above the replicated ones: its parent table indexes the whole coarser level, the coarse
+    // cells of other ranks have no child here
+    const bool mixed = dist() && C.replicated && !F.replicated;
+    if (dist() && F.replicated && !C.replicated) { set_error("replicated levels must be the coarsest ones"); return -1; }
     std::vector<uint32_t> children((size_t)nch * C.cstride, NO_CHILD);
     for (int f = 0; f < F.n_cells; ++f) {
       const int p = HF.parent[f], ch = HF.child[f];
@@ -990,7 +1020,7 @@ int agmg_ctx::ensure_transfers() {
     for (int p = 0; p < C.n_cells; ++p) {
       int n_kids = 0;
       for (int ch = 0; ch < nch; ++ch) n_kids += children[(size_t)ch * C.cstride + p] != NO_CHILD;
-      if (n_kids != nch && !(n_kids == 0 && ad.on)) { set_error("parent cell without 2^dim children (cells that are active on a coarse level need the active mesh set with AGMG_ACTIVE first)"); return -1; }
+      if (n_kids != nch && !(n_kids == 0 && (ad.on || mixed))) { set_error("parent cell without 2^dim children (cells that are active on a coarse level need the active mesh set with AGMG_ACTIVE first)"); return -1; }
     }
     for (int p = C.n_cells; p < C.cstride; ++p)
       for (int ch = 0; ch < nch; ++ch) children[(size_t)ch * C.cstride + p] = 0;
@@ -1006,7 +1036,7 @@ int agmg_ctx::ensure_transfers() {
         refined[p] = 0;
         for (int ch = 0; ch < nch; ++ch) children_dev[(size_t)ch * C.cstride + p] = 0;
       }
-    if (ad.on)
+    if (ad.on || mixed)
       for (int vel = 0; vel < 2; ++vel) {
         dfree(ad.rpull_ptr[vel ? 0 : 1][l]); dfree(ad.rpull_list[vel ? 0 : 1][l]);
         if (!childless) continue;
@@ -1069,7 +1099,7 @@ int agmg_ctx::ensure_transfers() {
 // ===================================================================== operators
 int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x, const EpiArgs &e) {
   const DeviceLevel &lv = L[l];
-  if (!dist()) {
+  if (!ldist(lv)) {
     if (which == 0) return op_velocity(lv, cd, AGMG_OP_A, x, nullptr, e);
     if (mass_ell(lv, cd)) return launch_mass_ell(stream, lv, cd, x, e);
     CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
@@ -1191,14 +1221,24 @@ int agmg_ctx::restrict_to(int which, int l, const double *src_fine, const EpiArg
   double *slots = vel ? slots_u : slots_p;
   if (dist()) CHECK(update_ghosts(vel ? F.xv : F.xp, src_fine));
   CHECK(launch_restrict_cells(stream, F, C, vel, src_fine, slots));
-  if (ad.on && ad.rpull_ptr[vel ? 0 : 1][l]) {
-    // local smoothing: the slots of the coarse cells without children hold nothing to pull (ensure_transfers)
+  const bool mixed = dist() && C.replicated && !F.replicated;
+  if ((ad.on || mixed) && l < (int)ad.rpull_ptr[vel ? 0 : 1].size() && ad.rpull_ptr[vel ? 0 : 1][l]) {
+    // local smoothing, or a replicated coarse level under a distributed one: the slots of the coarse cells without
+    // children (here) hold nothing to pull (ensure_transfers)
     DeviceLevel Cr = C;
     if (vel) { Cr.pull_ptr_v = ad.rpull_ptr[0][l]; Cr.pull_list_v = ad.rpull_list[0][l]; }
     else { Cr.pull_ptr_p = ad.rpull_ptr[1][l]; Cr.pull_list_p = ad.rpull_list[1][l]; }
-    return vel ? launch_pull_v(stream, Cr, slots, e) : launch_pull_p(stream, Cr, slots, 1, e);
+    CHECK(vel ? launch_pull_v(stream, Cr, slots, e) : launch_pull_p(stream, Cr, slots, 1, e));
+    if (!mixed) return 0;
+  } else if (mixed) {
+    CHECK(vel ? launch_pull_v(stream, C, slots, e) : launch_pull_p(stream, C, slots, 1, e));
   }
-  if (!dist()) return vel ? launch_pull_v(stream, C, slots, e) : launch_pull_p(stream, C, slots, 1, e);
+  if (mixed) {
+    // every rank restricted the cells it owns on the finer level: the defect of the replicated level is their sum
+    if (e.epi != EPI_STORE || e.x) { set_error("restriction onto a replicated level: store epilogue only"); return -1; }
+    return allreduce_vec(e.dst, vel ? (size_t)C.n_dofs_v() : (size_t)C.n_dofs_p());
+  }
+  if (!ldist(C)) return vel ? launch_pull_v(stream, C, slots, e) : launch_pull_p(stream, C, slots, 1, e);
   CHECK(vel ? launch_pull_v(stream, C, slots, e, PH_GHOST) : launch_pull_p(stream, C, slots, 1, e, PH_GHOST));
   CHECK(compress(vel ? C.xv : C.xp));
   return vel ? launch_pull_v(stream, C, slots, e, PH_OWNED) : launch_pull_p(stream, C, slots, 1, e, PH_OWNED);
@@ -1593,7 +1633,7 @@ int agmg_ctx::estimate_device(int which, int l) {
   if (gid) CHECK(vec_fill_gid_mod(stream, g, gid, which == 0 ? L[l].n_nodes_v : L[l].n_nodes_p, which == 0 ? L[l].dim : 1, 11));
   else CHECK(vec_fill_index_mod(stream, g, n, 11));
   double n_glob = (double)sp.n_dot;
-  CHECK(allreduce_host(&n_glob, 1));
+  if (!sp.local) CHECK(allreduce_host(&n_glob, 1));
   double sum = 0;
   {
     const size_t ng = (size_t)n_glob, full = ng / 11, rem = ng % 11;
@@ -1829,7 +1869,7 @@ int agmg_ctx::setup_smoothers() {
           coarse_pin_cap[w] = need;
         }
       }
-      else if (!dist() && use_batched_setup) batch.emplace_back(w, l);
+      else if (!ldist(L[l]) && use_batched_setup) batch.emplace_back(w, l);
       else CHECK(estimate_device(w, l));
     }
   if (!batch.empty()) CHECK(estimate_batched(batch));
@@ -2466,6 +2506,8 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
   }
   c->free_level(lv);
   lv.dim = dim;
+  lv.replicated = primary && c->dist() && d->replicated != 0;
+  if (lv.replicated && (has_plan || level == c->nl() - 1)) { set_error("a replicated level has no exchange plan and is not the finest level"); return -1; }
   lv.n_cells = d->n_cells; lv.n_nodes_v = d->n_nodes_v; lv.n_nodes_p = d->n_nodes_p;
   lv.cstride = (d->n_cells + 63) / 64 * 64;
   const size_t cs = lv.cstride;
@@ -2541,11 +2583,11 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
     if (!vel) {
       uint32_t max_val = 0;
       for (int i = 0; i < nn; ++i) max_val = std::max(max_val, ptr[i + 1] - ptr[i]);
-      lv.mass_fusable = !c->dist() && lv.n_cells <= MS_THREADS && (size_t)lv.n_cells * nloc <= (size_t)MS_MAX_SLOTS &&
+      lv.mass_fusable = !c->ldist(lv) && lv.n_cells <= MS_THREADS && (size_t)lv.n_cells * nloc <= (size_t)MS_MAX_SLOTS &&
                         nn <= MS_MAX_NODES && max_val <= 8;
       // column structure of the assembled mass rows: the nodes of the cells around each node,
       // ascending; a patch with more than 3^dim nodes (irregular vertex) keeps the matrix-free path
-      if (!c->dist() && c->use_ell) {
+      if (!c->ldist(lv) && c->use_ell) {
         const int W = NV;   // 3^dim
         const size_t npad = ((size_t)nn + 63) / 64 * 64;
         std::vector<uint32_t> col((size_t)W * npad);
@@ -2927,7 +2969,7 @@ static int set_coefficients_on(agmg_ctx *c, DeviceLevel &lv, CoeffData &cd, bool
   c->diag_ready = false; c->smoothers_ready = false;
   // brick levels: viscosity rows and cell extents in brick order (kernels_brickq.hip)
   c->dfree(cd.brick_geo);
-  if (lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && c->use_bricks && !c->dist()) {
+  if (lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && c->use_bricks && !c->ldist(lv)) {
     CHECK(c->dalloc(&cd.brick_geo, brick_geo_doubles(lv, cd.nqv)));
     CHECK(launch_brick_geo(c->stream, lv, cd));
     cd.bytes += brick_geo_doubles(lv, cd.nqv) * 8;
@@ -2936,7 +2978,7 @@ static int set_coefficients_on(agmg_ctx *c, DeviceLevel &lv, CoeffData &cd, bool
   if (cd.ell_stride != lv.ell_stride) { c->dfree(cd.ell_val); cd.ell_stride = 0; }
   // (not for the active-mesh coefficients: the solve only applies the level operators' mass
   // matrices; an active-mesh mass vmult keeps the matrix-free kernels)
-  if (lv.ell_col && c->use_ell && !c->dist() && level != AGMG_ACTIVE) {
+  if (lv.ell_col && c->use_ell && !c->ldist(lv) && level != AGMG_ACTIVE) {
     if (!cd.ell_val) CHECK(c->dalloc(&cd.ell_val, (size_t)lv.ell_w * lv.ell_stride));
     cd.ell_stride = lv.ell_stride;
     CHECK(launch_mass_ell_assemble(c->stream, lv, cd));
@@ -3314,7 +3356,17 @@ static int transfer_host(agmg_ctx *c, int which, int fine_level, bool prolong, d
   if (!rc) rc = c->h2d(dd, dst, nd);
   if (!rc) {
     if (prolong) rc = c->prolongate_from(vel ? 0 : 1, fine_level, dd, ds);
-    else {
+    else if (c->dist() && C.replicated && !F.replicated) {
+      // onto the last replicated level: the restriction stores the sum over ranks (constrained rows: zero), added here
+      double *tmp;
+      CHECK(c->dalloc(&tmp, ncz));
+      EpiArgs e;
+      e.epi = EPI_STORE; e.dst = tmp;
+      rc = c->restrict_to(vel ? 0 : 1, fine_level, ds, e);
+      if (!rc) rc = vec_axpy(c->stream, dd, 1.0, tmp, ncz);
+      if (!rc) rc = c->sync();
+      c->dfree(tmp);
+    } else {
       EpiArgs e;
       e.epi = EPI_ADD; e.dst = dd;
       rc = c->restrict_to(vel ? 0 : 1, fine_level, ds, e);

@@ -147,6 +147,7 @@ struct DeviceLevel {
   int dim = 3;
   int n_cells = 0, n_nodes_v = 0, n_nodes_p = 0;
   int n_owned_v = 0, n_owned_p = 0;  // owned nodes come first; == n_nodes_* on one rank
+  bool replicated = false;           // distributed context: every rank holds this level whole (agmg_level_desc::replicated)
   Exchange xv, xp;
   uint32_t *gid_v = nullptr, *gid_p = nullptr;  // global node index of each local node (nullptr: identity)
   int cstride = 0;                 // padded cell count (SoA row stride)

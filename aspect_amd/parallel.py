@@ -47,6 +47,18 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_concat(self, a):
+        """float64 arrays of equal shape on every rank -> their concatenation in rank order (set-up paths)."""
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.world == 1:
+            return a.copy()
+        dev = self.device if self.backend == "nccl" else None
+        mine = self.torch.from_numpy(a).to(dev) if dev is not None else self.torch.from_numpy(a)
+        parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return np.concatenate([t.cpu().numpy() for t in parts], axis=0)
+
     def close(self):
         if self.world > 1:
             self.dist.destroy_process_group()

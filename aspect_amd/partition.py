@@ -22,6 +22,17 @@ from __future__ import annotations
 import numpy as np
 
 
+def default_replicated_levels(n_global_cells, max_cells=4096):
+    """How many of the coarsest levels every rank holds whole (agmg_level_desc::replicated): those with at most
+    `max_cells` cells in the whole mesh -- a level that small costs a GPU its launch latency whether it holds an
+    eighth of it or all of it, and replicated it needs no message at all ("levels <= 3 have <= 512 cells
+    and go to the host or are gathered on one rank").  Never the finest level.  n_global_cells: per level, coarsest first."""
+    k = 0
+    while k < len(n_global_cells) - 1 and n_global_cells[k] <= max_cells:
+        k += 1
+    return k
+
+
 def cell_ranks(glev, size):
     """Owner rank of every cell of a global level (contiguous runs of coarse cells)."""
     # trees of the forest: the coarse cells of a box (reps), or of another geometry (n_trees: the shell's 96)
@@ -119,8 +130,11 @@ class _LocalVectors:
 class LocalLevel(_LocalVectors):
     """One rank's share of a ``boxmesh.Level``; duck-types it for ``capi.Solver``."""
 
-    def __init__(self, glev, rank, size):
+    def __init__(self, glev, rank, size, replicated=False, parent_is_replicated=False):
         self.dim, self.level = glev.dim, glev.level
+        self.replicated = bool(replicated) and size > 1
+        if self.replicated:          # the whole level, numbered as one rank would number it; no exchange plan
+            rank, size = 0, 1
         self.rank, self.size = rank, size
         crank = cell_ranks(glev, size)
         self.cells = np.flatnonzero(crank == rank)            # global cell ids, contiguous
@@ -145,13 +159,22 @@ class LocalLevel(_LocalVectors):
         self.global_nodes_v = self.v.l2g.astype(np.uint32)
         self.global_nodes_p = self.p.l2g.astype(np.uint32)
         self.n_global_nodes_v, self.n_global_nodes_p = glev.n_nodes_v, glev.n_nodes_p
+        if parent_is_replicated and size > 1:
+            # the first distributed level: its parents are cells of a level held whole (global cell order: the 2^dim
+            # children of a cell are consecutive)
+            nch = 1 << self.dim
+            self.parent_cell = (self.cells // nch).astype(np.int32)
+            self.child_index = (self.cells % nch).astype(np.uint8)
 
 
 class LocalHierarchy:
-    def __init__(self, ghier, rank, size):
+    def __init__(self, ghier, rank, size, n_replicated=0):
         self.dim = ghier.dim
         self.rank, self.size = rank, size
-        self.levels = [LocalLevel(g, rank, size) for g in ghier.levels]
+        self.n_replicated = min(int(n_replicated), len(ghier.levels) - 1) if size > 1 else 0
+        self.levels = [LocalLevel(g, rank, size, replicated=l < self.n_replicated,
+                                  parent_is_replicated=(l == self.n_replicated and l > 0))
+                       for l, g in enumerate(ghier.levels)]
 
     @property
     def finest(self):
@@ -166,13 +189,13 @@ class LocalProblem:
     """Rank-local view of a built ``cases.StokesProblem``: local tables, coefficient tables and
     right-hand side of the rank's subdomain (what each MPI rank of the reference holds)."""
 
-    def __init__(self, gproblem, rank, size):
+    def __init__(self, gproblem, rank, size, n_replicated=0):
         self.g = gproblem
         self.rank, self.size = rank, size
         for k in ("name", "dim", "tol", "restart", "n_cheap", "n_expensive", "krylov", "idr_s",
                   "pressure_scaling", "eta_min", "eta_max", "is_compressible"):
             setattr(self, k, getattr(gproblem, k, None))
-        self.hier = LocalHierarchy(gproblem.hier, rank, size)
+        self.hier = LocalHierarchy(gproblem.hier, rank, size, n_replicated)
         self.eta_levels = [np.ascontiguousarray(t[lev.cells]) for t, lev in zip(gproblem.eta_levels, self.hier.levels)]
         self.eta_active = np.ascontiguousarray(gproblem.eta_active[self.hier.finest.cells])
         fin = self.hier.finest
@@ -286,8 +309,12 @@ class RankLocalBoxLevel(_LocalVectors):
     coefficient and right-hand side builders to run on the rank's cells.  Cartesian, non-periodic, lexicographic
     global numbering."""
 
-    def __init__(self, dim, extents, reps, l, bc, rank, size):
+    def __init__(self, dim, extents, reps, l, bc, rank, size, replicated=False, parent_is_replicated=False):
         from . import boxmesh as bm
+        self.replicated = bool(replicated) and size > 1
+        true_rank, true_size = rank, size
+        if self.replicated:          # the whole level, as one rank would hold it; no exchange plan
+            rank, size = 0, 1
         self.dim, self.level, self.rank, self.size = dim, l, rank, size
         self.extents = np.asarray(extents, dtype=np.float64)
         self.reps = np.asarray(reps, dtype=np.int64)
@@ -338,6 +365,10 @@ class RankLocalBoxLevel(_LocalVectors):
         self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
         self.global_nodes_v = self.v.l2g.astype(np.uint32)
         self.global_nodes_p = self.p.l2g.astype(np.uint32)
+        if parent_is_replicated and true_size > 1:
+            nch = 1 << dim
+            self.parent_cell = (self.cells // nch).astype(np.int32)
+            self.child_index = (self.cells % nch).astype(np.uint8)
 
     # -- the part of boxmesh.Level's interface the table builders use, on the rank's cells and nodes
     def node_coords_v(self):
@@ -398,10 +429,13 @@ class RankLocalBoxLevel(_LocalVectors):
 
 
 class RankLocalHierarchy:
-    def __init__(self, dim, refinement, extents, reps, bc, rank, size, only_finest=False):
+    def __init__(self, dim, refinement, extents, reps, bc, rank, size, only_finest=False, n_replicated=0):
         self.dim, self.rank, self.size = dim, rank, size
         first = refinement if only_finest else 0
-        self.levels = [RankLocalBoxLevel(dim, extents, reps, l, bc, rank, size) for l in range(first, refinement + 1)]
+        self.n_replicated = 0 if (only_finest or size == 1) else min(int(n_replicated), refinement)
+        self.levels = [RankLocalBoxLevel(dim, extents, reps, l, bc, rank, size, replicated=l < self.n_replicated,
+                                         parent_is_replicated=(l == self.n_replicated and l > 0))
+                       for l in range(first, refinement + 1)]
 
     @property
     def finest(self):
@@ -418,8 +452,13 @@ class RankLocalProblem:
     rank's cells plus the one layer of neighbouring cells that share its nodes (same sums as the global assembly up
     to their order).  eta_min / eta_max are the rank's own (reporting only)."""
 
-    def __init__(self, case, rank, size, only_finest=False):
+    def __init__(self, case, rank, size, only_finest=False, n_replicated=0, gather=None):
+        """n_replicated: the levels 0..n_replicated-1 are held whole by every rank (agmg_level_desc::replicated); their
+        coefficient tables need the cell values of the coarsest distributed level of ALL ranks: `gather(array)` returns
+        the arrays of all ranks concatenated in rank order (parallel.Ranks.gather_concat)."""
         from . import boxmesh as bm
+        if n_replicated and size > 1 and gather is None:
+            raise ValueError("replicated levels need a gather over the ranks for their coefficient tables")
         if case.deform is not None or case.periodic or case.make_hierarchy is not None or case.numbering != "lexicographic":
             raise ValueError("rank-local set-up: Cartesian non-periodic boxes with lexicographic numbering only")
         if case.boundary_traction or case.dilation_rhs is not None or case.free_surface_spec or case.boundary_velocity or \
@@ -431,7 +470,7 @@ class RankLocalProblem:
         dim = case.dim
         extents = [1.0] * dim if case.extents is None else case.extents
         reps = [1] * dim if case.reps is None else case.reps
-        self.hier = RankLocalHierarchy(dim, case.refinement, extents, reps, case.bc, rank, size, only_finest)
+        self.hier = RankLocalHierarchy(dim, case.refinement, extents, reps, case.bc, rank, size, only_finest, n_replicated)
         fin = self.hier.finest
         if only_finest:
             nq = 3 ** dim
@@ -440,7 +479,9 @@ class RankLocalProblem:
             self.eta_levels = [self.eta_active]
             self.eta_min, self.eta_max = float(self.eta_active.min()), float(self.eta_active.max())
         else:
-            self.eta_active, self.eta_levels, self.eta_min, self.eta_max = bm.viscosity_tables(self.hier, case.eta, case.averaging)
+            self.eta_active, self.eta_levels, self.eta_min, self.eta_max = bm.viscosity_tables(
+                self.hier, case.eta, case.averaging, gather=gather if self.hier.n_replicated else None,
+                n_replicated=self.hier.n_replicated)
         self.free_surface = None
         self.dilation = None
         # right-hand side: own cells, then the halo cells' shares of the rank's nodes

@@ -111,6 +111,7 @@ def main():
 
     transport_name = ""
     comm_counts = {}
+    replicated_levels = {}
 
     def distributed_setup(refinement=None):
         nonlocal transport_name
@@ -124,7 +125,14 @@ def main():
         # (tests/test_host_and_abi.py: the tables equal the partition of the global mesh entry for entry)
         g = cases.convection_box(3, refinement or args.refinement)
         g.reps, g.extents = reps, [float(r) for r in reps]
-        loc = partition.RankLocalProblem(g, rank, world)
+        # the coarsest levels (at most 4096 cells in the whole mesh) are held whole by every rank: no ghost exchange on
+        # them, one sum over ranks where the V-cycle steps onto them (AGMG_REPLICATED=<k> overrides, 0 = every level
+        # partitioned as in the reference)
+        ref_ = refinement or args.refinement
+        n_rep = partition.default_replicated_levels([world * 8 ** l for l in range(ref_ + 1)])
+        n_rep = int(os.environ.get("AGMG_REPLICATED", n_rep))
+        replicated_levels[ref_] = n_rep
+        loc = partition.RankLocalProblem(g, rank, world, n_replicated=n_rep, gather=ranks.gather_concat)
         lf = loc.hier.finest
         src_l = np.sin(0.37 * loc.global_index_vector())          # the same global vector as on one rank
         src_l[:lf.n_dofs_v][lf.constrained_dofs_v()] = 0.0
@@ -149,7 +157,8 @@ def main():
             _, rep_c, _ = solver.solve(allow_failure=True)
             its = max(1, rep_c.n_cheap_iterations + rep_c.n_expensive_iterations)
             comm_counts.update({"gmres_iterations": its, "ghost_exchanges_per_iteration": (tr0.n_exchange - e0) / its,
-                                "all_reduces_per_iteration": (tr0.n_allreduce - a0) / its})
+                                "all_reduces_per_iteration": (tr0.n_allreduce - a0) / its,
+                                "replicated_coarse_levels": n_rep, "levels": ref_ + 1})
         transport_name = "torch.distributed callbacks"
         want = os.environ.get("AGMG_TRANSPORT", "rccl" if backend == "nccl" else "torch")
         if want == "rccl":
@@ -189,7 +198,8 @@ def main():
             sys.exit(3)
         else:
             parallelism = (f"{world} subdomains (one unit cube per GPU), ghost update + compress per vmult and "
-                           f"all-reduce per dot product; transport: {transport_name}")
+                           f"all-reduce per dot product; the {replicated_levels.get(args.refinement, 0)} coarsest multigrid "
+                           f"levels replicated on every rank; transport: {transport_name}")
     else:
         prob, solver, fin, src_h, nu, npd = serial_setup()
     n = nu + npd

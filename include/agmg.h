@@ -177,6 +177,18 @@ typedef struct agmg_level_desc {
   int32_t n_copy_v, n_copy_p;
   const uint32_t *copy_active_v; const uint32_t *copy_level_v;
   const uint32_t *copy_active_p; const uint32_t *copy_level_p;
+  /* Distributed contexts (world_size > 1): 1 = every rank holds this level WHOLE, with the same tables in the
+   * same (global) numbering, and no exchange plan (n_neighbors == 0, every node owned).  SURVEY.md 8e: "levels
+   * <= 3 have <= 512 cells and go to the host or are gathered on one rank": here they are replicated instead, so
+   * that nobody waits for anybody.  Operators, smoothers, eigenvalue estimates and the coarse solve of such a
+   * level run as on one rank (no ghost exchange, no all-reduce; the one-launch smoother sequences, the assembled
+   * mass rows and the host-resident level 0 apply); the restriction from the first distributed level onto the
+   * last replicated one ends in ONE sum over ranks of the coarse defect (every rank restricts the cells it owns
+   * on the finer level: parent_cell of that level indexes the whole coarser level, and coarse cells without a
+   * child on this rank take no part), the prolongation back needs no message.  Replicated levels are the
+   * levels 0..k for some k; the finest level is never replicated.  (No counterpart in the reference: deal.II
+   * partitions every level.) */
+  int32_t replicated;
 } agmg_level_desc;
 
 /* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */

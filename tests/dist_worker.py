@@ -9,6 +9,7 @@ usage: dist_worker.py <case> <backend: gloo|nccl|gloo-dev> [what: all|ops|vmult]
 All ranks may share one GPU (gloo: the library stages messages through host memory; gloo-dev: the
 library hands out device pointers as it does for RCCL and the transport stages them itself)."""
 import os
+import re
 import sys
 
 import numpy as np
@@ -28,8 +29,15 @@ def relerr(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
+def split_replicated(case):
+    """'<case>_rep<k>': the levels 0..k-1 are held whole by every rank (agmg_level_desc::replicated)."""
+    m = re.match(r"(.*)_rep(\d+)$", case)
+    return (m.group(1), int(m.group(2))) if m else (case, 0)
+
+
 def global_problem(case, world, build=True):
     reps = {1: [1, 1, 1], 2: [2, 1, 1], 4: [2, 2, 1], 8: [2, 2, 2]}[world]
+    case = split_replicated(case)[0]
     if case.endswith("_ranklocal"):   # partition.RankLocalProblem: every rank builds its own subdomain only
         case = case[:-len("_ranklocal")]
     if case == "nsinker":
@@ -73,12 +81,14 @@ def main():
     ranks = parallel.Ranks(backend=backend.split("-")[0], device=dev)
     tr = parallel.Transport(ranks, device_buffers=1 if backend == "gloo-dev" else None)
     g = global_problem(case, ranks.world)
+    case, n_rep = split_replicated(case)
     if case.endswith("_ranklocal"):
         # the rank's tables in closed form from its own subdomain (no global mesh on the product side; the global
         # problem above is the serial oracle's)
-        loc = partition.RankLocalProblem(global_problem(case, ranks.world, build=False), ranks.rank, ranks.world)
+        loc = partition.RankLocalProblem(global_problem(case, ranks.world, build=False), ranks.rank, ranks.world,
+                                         n_replicated=n_rep, gather=ranks.gather_concat)
     else:
-        loc = partition.LocalProblem(g, ranks.rank, ranks.world)
+        loc = partition.LocalProblem(g, ranks.rank, ranks.world, n_replicated=n_rep)
     hip = capi.Solver(capi.load(), loc, transport=tr, device=dev.index)
     ora = pyoracle.solver(g)
     fails = []
@@ -188,7 +198,7 @@ def main():
               1e-9 * ro.solver_tolerance + g.tol * 1e-12 * rhs_norm)
         check("solution", relerr(xg[:nu_o], xo[go_]), 1e-4 if rhs_norm < 1e6 else 5e-3)
         if ranks.rank == 0:
-            print(f"[dist] {case} world={ranks.world} backend={backend}: iterations {rg.n_cheap_iterations} "
+            print(f"[dist] {case} replicated levels {n_rep} world={ranks.world} backend={backend}: iterations {rg.n_cheap_iterations} "
                   f"(oracle {ro.n_cheap_iterations}), exchanges {tr.n_exchange}, all-reduces {tr.n_allreduce}", flush=True)
     if case in ("nsinker_r3", "box3d_r3"):
         # deal.II's cell_loop overlaps the ghost import with the interior cells; here: interior blocks

@@ -72,6 +72,10 @@ def test_world_size_2_gloo_partition_and_transport():
                                              (2, "nsinker_r3_ranklocal", "gloo-dev"), (8, "box3d_ranklocal", "gloo"),
                                              # configs[4] in small (one r4 cube per rank, per-q viscosity), rank-local set-up
                                              (2, "box3d_r4_ranklocal", "gloo-dev"), (8, "box3d_r4_ranklocal", "gloo"),
+                                             # the coarsest levels held whole by every rank (no exchange on them, one sum over ranks in the
+                                             # restriction onto the last of them)
+                                             (8, "box3d_rep1", "gloo"), (2, "nsinker_r3_rep2", "gloo"), (4, "box3d_r3_rep2", "gloo-dev"),
+                                             (4, "box2d_rep2", "gloo"), (2, "box3d_r4_ranklocal_rep3", "gloo-dev"), (2, "nsinker_idr_rep1", "gloo"),
                                              # device-pointer protocol of the communicator (what RCCL uses)
                                              (2, "nsinker_harmonic", "gloo-dev"), (4, "box3d", "gloo-dev")])
 def test_distributed_hip_matches_serial_oracle(nproc, case, wire):

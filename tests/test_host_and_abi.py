@@ -170,3 +170,70 @@ def test_rank_local_setup_equals_partition_of_the_global_mesh(refinement, reps, 
         x = np.arange(g.hier.finest.n_dofs_v + g.hier.finest.n_dofs_p, dtype=np.float64)
         assert np.array_equal(a.to_local(x), b.to_local(x)) and np.array_equal(b.to_local(x), b.global_index_vector())
         assert all(np.array_equal(p, q) for p, q in zip(a.owned_block(), b.owned_block()))
+
+
+@pytest.mark.parametrize("averaging", ["harmonic", "project_q1"])
+def test_replicated_coarse_levels_of_the_host_partitions(averaging):
+    """agmg_level_desc::replicated on the host side: the levels 0..k-1 of both partitions (cut out of the global mesh /
+    generated per rank) are the global levels themselves, without an exchange plan; the first distributed level names
+    its parents in the whole coarser level; the coefficient tables of the replicated levels, which the rank-local
+    set-up forms from a gather of the coarsest distributed level, equal the global ones bit for bit."""
+    from aspect_amd import boxmesh as bm
+    from aspect_amd import partition
+    size, reps, k = 4, [2, 2, 1], 2
+
+    def case():
+        c = cases.nsinker_box(3, n_sinkers=4, ratio=1e4, averaging=bm.AVG_HARMONIC if averaging == "harmonic" else bm.AVG_PROJECT_Q1)
+        c.reps, c.extents = reps, [float(x) for x in reps]
+        return c
+
+    g = case().build()
+    assert partition.default_replicated_levels([lv.n_cells for lv in g.hier.levels], max_cells=300) == 3
+    assert partition.default_replicated_levels([lv.n_cells for lv in g.hier.levels], max_cells=10 ** 9) == g.hier.n_levels - 1
+    for rank in range(size):
+        a = partition.LocalProblem(g, rank, size, n_replicated=k)
+        for l in range(g.hier.n_levels):
+            la, gl = a.hier.levels[l], g.hier.levels[l]
+            assert la.replicated == (l < k)
+            if l < k:
+                assert la.n_cells == gl.n_cells and la.n_owned_nodes_v == la.n_nodes_v == gl.n_nodes_v and not la.neighbors
+                assert np.array_equal(la.cell_nodes_v, gl.cell_nodes_v) and np.array_equal(la.cmask_v, gl.cmask_v)
+                assert np.array_equal(a.eta_levels[l], g.eta_levels[l])
+            if l == k:
+                assert np.array_equal(la.parent_cell, la.cells // 8) and np.array_equal(la.child_index, la.cells % 8)
+                assert la.parent_cell.max() < g.hier.levels[l - 1].n_cells
+            else:
+                assert not hasattr(la, "parent_cell")
+    # rank-local set-up with a real gather: all ranks in lock step (threads stand in for the processes)
+    import threading
+    results, slots, barrier = [None] * size, {}, threading.Barrier(size)
+
+    def worker(rank):
+        calls = [0]
+
+        def gather(arr):
+            key = calls[0]
+            calls[0] += 1
+            slots[(key, rank)] = np.array(arr, dtype=np.float64)
+            barrier.wait()
+            out = np.concatenate([slots[(key, r)] for r in range(size)], axis=0)
+            barrier.wait()
+            return out
+        results[rank] = partition.RankLocalProblem(case(), rank, size, n_replicated=k, gather=gather)
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for rank in range(size):
+        b, a = results[rank], partition.LocalProblem(g, rank, size, n_replicated=k)
+        assert b is not None
+        for l in range(g.hier.n_levels):
+            la, lb = a.hier.levels[l], b.hier.levels[l]
+            for key in ("n_cells", "n_nodes_v", "n_owned_nodes_v", "n_nodes_p", "cell_nodes_v", "cell_nodes_p", "cmask_v", "neighbors"):
+                assert np.array_equal(np.asarray(getattr(la, key)), np.asarray(getattr(lb, key))), (rank, l, key)
+            assert lb.replicated == (l < k)
+            if l == k:
+                assert np.array_equal(la.parent_cell, lb.parent_cell) and np.array_equal(la.child_index, lb.child_index)
+            assert np.array_equal(a.eta_levels[l], b.eta_levels[l]), (rank, l)
