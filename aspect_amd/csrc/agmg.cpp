@@ -362,7 +362,7 @@ struct agmg_ctx {
   }
   int build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv,
                          const std::vector<uint32_t> &send_nodes);
-  int build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv);
+  int build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv, const std::vector<uint32_t> &send_nodes);
   // quad-per-cell brick kernel (kernels_brickq.hip) for the A block of structured Cartesian 3-D levels: faster than
   // the block kernels from 512 cubes of 8^3 cells on (r6: 121 -> 99 us, r7: 891 -> 776 us), slower below (r5: 23.3 ->
   // 24.5 us), so by default only those levels get brick tables.  AGMG_BRICKS=1: every level that tiles into
@@ -370,7 +370,7 @@ struct agmg_ctx {
   int use_bricks = 2;       // 0 off, 1 every level that qualifies, 2 large levels only
   int brick_z_override = 0; // AGMG_BRICK_Z: layers per brick (1, 2, 4 or 8) instead of the size-based choice
   int brick_stack_override = 0; // AGMG_BRICK_STACK: cubes per brick along z (1, 2 or 4) instead of the size-based choice
-  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && !ldist(lv); }
+  bool bricks_on(const DeviceLevel &lv) const { return use_bricks && lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN; }
   int ensure_workspace();
   int ensure_transfers();
   int ensure_mg_vectors();
@@ -437,6 +437,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8); dfree(l.bt.lidT);
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list); dfree(l.bt.blk_order);
   dfree(l.bk.gnode); dfree(l.bk.bcell); dfree(l.bk.pidx); dfree(l.bk.fx_nodes); dfree(l.bk.fx_ptr); dfree(l.bk.fx_list);
+  dfree(l.bk.gh_nodes); dfree(l.bk.gh_ptr); dfree(l.bk.gh_list);
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.gid_v); dfree(l.gid_p);
   dfree(l.ell_col); dfree(l.coeff.ell_val); dfree(l.coeff.brick_geo);
@@ -615,10 +616,10 @@ int agmg_ctx::build_block_tables(DeviceLevel &lv, const HostLevel &hl, const std
 // 8 x 8 x 8 cells and the cubes into bricks of Z layers.  Every lattice position of a brick must
 // receive the same node from all cells around it, every cube must be complete and every cell must
 // land in a brick: otherwise the level keeps the block path (returns 0 with bk.built == false).
-int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv) {
+int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std::vector<uint8_t> &cmv, const std::vector<uint32_t> &send_nodes) {
   BrickTables &bk = lv.bk;
   const int n = lv.n_cells, nn = lv.n_nodes_v;
-  if (lv.dim != 3 || n < 512 || n % 512 != 0 || (unsigned)nn > BRICK_NODE_MASK || ldist(lv)) return 0;
+  if (lv.dim != 3 || n < 512 || n % 512 != 0 || (unsigned)nn > BRICK_NODE_MASK) return 0;
   if (lv.geom != AGMG_GEOM_CARTESIAN) return 0;                 // (the brick kernel reads cell extents)
   if (use_bricks == 2 && n < 512 * 512) return 0;               // small levels: the block kernels are faster
   const uint32_t *cnv = hl.cnv.data();
@@ -769,13 +770,41 @@ int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std
           }
     }
   // ownership: the first brick (and lattice position) that lists a node owns it
+  // (distributed levels: a ghost node is owned by no brick, every share of it goes through a partial slot)
+  const uint32_t n_owned = (uint32_t)lv.n_owned_v;
+  bk.n_interior = 0;
+  if (n_owned < (uint32_t)nn) {
+    // bricks without a ghost node first: they run while the ghost import is in flight (deal.II's cell_loop overlaps
+    // the same way, matrix_free_operators.cc:357, 794); the order inside the two groups stays
+    std::vector<int> order;
+    std::vector<uint8_t> iface(nb, 0);
+    for (int brick = 0; brick < nb; ++brick)
+      for (int l = 0; l < latn && !iface[brick]; ++l) iface[brick] = gnode[(size_t)brick * latn + l] >= n_owned;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int brick = 0; brick < nb; ++brick)
+        if (iface[brick] == pass) order.push_back(brick);
+    for (int brick = 0; brick < nb; ++brick) bk.n_interior += !iface[brick];
+    std::vector<uint32_t> g2(gnode.size()), c2(bcell.size());
+    for (int k = 0; k < nb; ++k) {
+      std::copy(gnode.begin() + (size_t)order[k] * latn, gnode.begin() + (size_t)(order[k] + 1) * latn, g2.begin() + (size_t)k * latn);
+      std::copy(bcell.begin() + (size_t)order[k] * Z * 64, bcell.begin() + (size_t)(order[k] + 1) * Z * 64, c2.begin() + (size_t)k * Z * 64);
+    }
+    gnode.swap(g2); bcell.swap(c2);
+  }
+  if ((uint64_t)nb * npb + send_nodes.size() > 0xFFFFFFF0ull) return 0;
   std::vector<uint32_t> owner(nn, 0xFFFFFFFFu), fx_count(nn, 0);
   std::vector<std::pair<uint32_t, uint32_t>> pairs;   // (node, partial slot)
   for (int brick = 0; brick < nb; ++brick)
     for (int l = 0; l < latn; ++l) {
       uint32_t &e = gnode[(size_t)brick * latn + l];
       const uint32_t node = e;
-      if (owner[node] == 0xFFFFFFFFu) {
+      if (node >= n_owned) {
+        if (pidx[l] == 0xFFFF) return 0;   // a ghost node inside a brick
+        owner[node] = 0xFFFFFFFEu;
+        e = node | BRICK_PARTIAL | ((uint32_t)cmv[node] << 29);
+        pairs.emplace_back(node, (uint32_t)((size_t)brick * npb + pidx[l]));
+        ++fx_count[node];
+      } else if (owner[node] == 0xFFFFFFFFu) {
         owner[node] = (uint32_t)((size_t)brick * latn + l);
         e = node | ((uint32_t)cmv[node] << 29);
       } else {
@@ -788,21 +817,35 @@ int agmg_ctx::build_brick_tables(DeviceLevel &lv, const HostLevel &hl, const std
   for (int node = 0; node < nn; ++node)
     if (owner[node] == 0xFFFFFFFFu) return 0;   // a node no cell touches
   std::vector<uint32_t>().swap(owner);
-  std::vector<uint32_t> fx_nodes, fx_ptr(1, 0), fx_index(nn, 0), fx_list(pairs.size());
+  // remote partial sums of the owned nodes other ranks ghost: entry k of the receive buffer belongs to send_nodes[k]
+  for (uint32_t node : send_nodes) {
+    if (node >= n_owned) return 0;
+    ++fx_count[node];
+  }
+  // owned nodes [0, n_owned) form the fix-up lists, ghost nodes the lists of the compress step
+  std::vector<uint32_t> fx_nodes, fx_ptr(1, 0), fx_index(nn, 0), gh_nodes, gh_ptr(1, 0);
   for (int node = 0; node < nn; ++node)
     if (fx_count[node]) {
-      fx_index[node] = (uint32_t)fx_nodes.size();
-      fx_nodes.push_back((uint32_t)node | ((uint32_t)cmv[node] << 29));
-      fx_ptr.push_back(fx_ptr.back() + fx_count[node]);
+      std::vector<uint32_t> &nodes = (uint32_t)node < n_owned ? fx_nodes : gh_nodes, &ptr = (uint32_t)node < n_owned ? fx_ptr : gh_ptr;
+      fx_index[node] = (uint32_t)nodes.size();
+      nodes.push_back((uint32_t)node < n_owned ? ((uint32_t)node | ((uint32_t)cmv[node] << 29)) : (uint32_t)node);
+      ptr.push_back(ptr.back() + fx_count[node]);
     }
-  std::vector<uint32_t> fill(fx_ptr.begin(), fx_ptr.end() - 1);
-  for (auto &pr : pairs) fx_list[fill[fx_index[pr.first]]++] = pr.second;   // pairs are in brick order
+  std::vector<uint32_t> fx_list(fx_ptr.back()), gh_list(gh_ptr.back());
+  std::vector<uint32_t> fill(fx_ptr.begin(), fx_ptr.end() - 1), gfill(gh_ptr.begin(), gh_ptr.end() - 1);
+  for (auto &pr : pairs) {   // pairs are in brick order
+    if (pr.first < n_owned) fx_list[fill[fx_index[pr.first]]++] = pr.second;
+    else gh_list[gfill[fx_index[pr.first]]++] = pr.second;
+  }
+  for (size_t k = 0; k < send_nodes.size(); ++k) fx_list[fill[fx_index[send_nodes[k]]]++] = (uint32_t)((size_t)nb * npb + k);
   bk.Z = Z; bk.n_bricks = nb; bk.latn = latn; bk.npb = npb;
   bk.n_fix = (int)fx_nodes.size();
   bk.n_partial_slots = (size_t)nb * npb;
   CHECK(upload(&bk.gnode, gnode)); CHECK(upload(&bk.bcell, bcell)); CHECK(upload(&bk.pidx, pidx));
   CHECK(upload(&bk.fx_nodes, fx_nodes)); CHECK(upload(&bk.fx_ptr, fx_ptr)); CHECK(upload(&bk.fx_list, fx_list));
-  bk.bytes = (gnode.size() + bcell.size() + fx_nodes.size() + fx_ptr.size() + fx_list.size()) * 4 + pidx.size() * 2;
+  bk.n_gh = (int)gh_nodes.size();
+  if (bk.n_gh) { CHECK(upload(&bk.gh_nodes, gh_nodes)); CHECK(upload(&bk.gh_ptr, gh_ptr)); CHECK(upload(&bk.gh_list, gh_list)); }
+  bk.bytes = (gnode.size() + bcell.size() + fx_nodes.size() + fx_ptr.size() + fx_list.size() + gh_nodes.size() + gh_ptr.size() + gh_list.size()) * 4 + pidx.size() * 2;
   bk.built = true;
   return 0;
 }
@@ -1106,6 +1149,22 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
     return launch_pull_p(stream, lv, slots_p, 1, e);
   }
   // distributed: src.update_ghost_values(); cell loop; dst.compress(add); epilogue on the owned rows
+  if (which == 0 && bricks_on(lv) && brickq_supported(lv, cd, AGMG_OP_A) &&
+      (e.epi == EPI_STORE || e.epi == EPI_RESID || e.epi == EPI_CHEB)) {
+    // brick levels: ghost import, the brick kernel (shares of ghost nodes and of rows another brick owns go to partial
+    // slots), the ghost sums to their owners, then the fix-up of the owned rows with the received sums
+    if (use_overlap && cstream && lv.bk.n_interior > 0 && lv.xv.active()) {
+      CHECK(begin_import([&] { return update_ghosts(lv.xv, x); }));
+      CHECK(launch_op_bricks(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, slots_p, e, nullptr, PH_INTERIOR));
+      CHECK(end_import());
+      CHECK(launch_op_bricks(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, slots_p, e, nullptr, PH_INTERFACE));
+    } else {
+      CHECK(update_ghosts(lv.xv, x));
+      CHECK(launch_op_bricks(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, slots_p, e, nullptr, PH_GHOST));
+    }
+    CHECK(compress(lv.xv));
+    return launch_op_bricks(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, slots_p, e, nullptr, PH_OWNED);
+  }
   if (which == 0) {
     if (can_overlap(lv, e, cd, AGMG_OP_A)) {
       CHECK(begin_import([&] { return update_ghosts(lv.xv, x); }));
@@ -2668,7 +2727,7 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
   tm.lap("block tables", level);
   lv.bytes_tables += lv.bt.bytes;
   if (c->use_bricks && structured) {   // (not for the partly refined meshes of adaptive contexts)
-    CHECK(c->build_brick_tables(lv, hl, cmv));
+    CHECK(c->build_brick_tables(lv, hl, cmv, send_nodes_of(0)));
     lv.bytes_tables += lv.bk.bytes;
   }
   CHECK(c->dalloc(&lv.inv_diag_A, (size_t)lv.n_dofs_v()));
@@ -2969,7 +3028,7 @@ static int set_coefficients_on(agmg_ctx *c, DeviceLevel &lv, CoeffData &cd, bool
   c->diag_ready = false; c->smoothers_ready = false;
   // brick levels: viscosity rows and cell extents in brick order (kernels_brickq.hip)
   c->dfree(cd.brick_geo);
-  if (lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && c->use_bricks && !c->ldist(lv)) {
+  if (lv.bk.built && lv.geom == AGMG_GEOM_CARTESIAN && c->use_bricks) {
     CHECK(c->dalloc(&cd.brick_geo, brick_geo_doubles(lv, cd.nqv)));
     CHECK(launch_brick_geo(c->stream, lv, cd));
     cd.bytes += brick_geo_doubles(lv, cd.nqv) * 8;

@@ -125,6 +125,14 @@ struct BrickTables {
   uint32_t *fx_ptr = nullptr;   // [n_fix + 1]
   uint32_t *fx_list = nullptr;  // partial slots (brick * npb + surface index), brick order
   size_t n_partial_slots = 0;   // n_bricks * npb (doubles needed: * 3)
+  // distributed levels: a ghost node is owned by no brick (every brick writes its share to a partial slot); the sums
+  // of the ghost nodes go to Exchange::ghostbuf for the compress step, and the fx lists of owned nodes that other
+  // ranks ghost carry entries >= n_partial_slots addressing the receive buffer (remote partial sums)
+  int n_interior = 0;           // bricks [0, n_interior) touch no ghost node: they run while the ghost import is in flight
+  int n_gh = 0;
+  uint32_t *gh_nodes = nullptr; // [n_gh] ghost node
+  uint32_t *gh_ptr = nullptr;   // [n_gh + 1]
+  uint32_t *gh_list = nullptr;  // partial slots, brick order
   size_t bytes = 0;
 };
 
@@ -269,14 +277,19 @@ int launch_face_add_received(hipStream_t s, int dim, const FaceTerm &ft, const u
 
 // brick path (kernels_brick.hip): whole operator application on a level with BrickTables; partial sums go
 // to `partials` (3 * n_partial_slots doubles).  ep (Stokes): also finish the pressure rows.
+// phase (distributed levels, as launch_op): PH_GHOST = main kernel + sums of the ghost nodes into Exchange::ghostbuf
+// (or PH_INTERIOR = the main kernel over the bricks without a ghost node, then PH_INTERFACE = the other bricks + the
+// ghost sums), PH_OWNED = the fix-up of the owned rows including the received remote partial sums
 int launch_op_bricks(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
-                     const double *src_p, double *partials, double *slots_p, const EpiArgs &eu, const EpiArgs *ep);
+                     const double *src_p, double *partials, double *slots_p, const EpiArgs &eu, const EpiArgs *ep,
+                     int phase = 0 /* PH_ALL */);
 // quad-per-cell brick kernels (kernels_brickq.hip): main kernel only, the fix-up is launch_op_bricks'
 bool brickq_supported(const DeviceLevel &L, const CoeffData &cd, int which);
 size_t brick_geo_doubles(const DeviceLevel &L, int nqv);
 int launch_brick_geo(hipStream_t s, const DeviceLevel &L, const CoeffData &cd);
+// bricks [brick0, brick0 + n_launch) (n_launch < 0: all from brick0 on)
 int launch_brickq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u, const double *src_p,
-                  double *partials, double *slots_p, const EpiArgs &eu);
+                  double *partials, double *slots_p, const EpiArgs &eu, int brick0 = 0, int n_launch = -1);
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks,
               int phase = PH_ALL, const EpiArgs *ep = nullptr);

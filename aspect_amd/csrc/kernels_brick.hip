@@ -22,7 +22,13 @@ struct BrickFixArgs {
   const double *partials;
   int n_fix;
   EpiArgs e;
+  // distributed levels: list entries >= recv_base address the receive buffer of the ghost exchange
+  uint32_t recv_base;
+  const double *recv;
 };
+__device__ __forceinline__ const double *brick_partial(const BrickFixArgs &F, const uint32_t ent) {
+  return ent >= F.recv_base ? F.recv + (size_t)(ent - F.recv_base) * 3 : F.partials + (size_t)ent * 3;
+}
 // One thread per node that receives partial sums.  The loads go out in three dependent rounds instead of one per
 // list entry: (row bounds, node word) -> (the first FX_PRE list entries, clamped) + the row itself and the
 // epilogue's coefficient -> the partial sums; longer rows finish in a loop.  Same order of additions as the list.
@@ -45,7 +51,7 @@ __device__ __forceinline__ void brick_fix_body(const BrickFixArgs &F, const unsi
   double part[FX_PRE][3];
 #pragma unroll
   for (int k = 0; k < FX_PRE; ++k) {
-    const double *p = F.partials + (size_t)ent[k] * 3;
+    const double *p = brick_partial(F, ent[k]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) part[k][c] = p[c];
   }
@@ -57,7 +63,7 @@ __device__ __forceinline__ void brick_fix_body(const BrickFixArgs &F, const unsi
       for (int c = 0; c < 3; ++c) sum[c] += part[k][c];
     }
   for (uint32_t k = s + FX_PRE; k < en; ++k) {
-    const double *p = F.partials + (size_t)F.fx_list[k] * 3;
+    const double *p = brick_partial(F, F.fx_list[k]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) sum[c] += p[c];
   }
@@ -68,6 +74,23 @@ __device__ __forceinline__ void brick_fix_body(const BrickFixArgs &F, const unsi
   }
 }
 __global__ void __launch_bounds__(256) k_brick_fix(const BrickFixArgs F) { brick_fix_body(F, blockIdx.x); }
+// distributed levels: the sum of the partial slots of every ghost node, brick order, into the send buffer of the compress
+// step (ghost_out[(node - n_owned) * 3 + c]; the owner adds it to its row in its own fix-up)
+__global__ void __launch_bounds__(256) k_brick_ghost(const uint32_t *__restrict__ gh_nodes, const uint32_t *__restrict__ gh_ptr,
+                                                     const uint32_t *__restrict__ gh_list, const double *__restrict__ partials,
+                                                     double *__restrict__ ghost_out, const int n_gh, const int n_owned) {
+  const int n = (int)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_gh) return;
+  double sum[3] = {0.0, 0.0, 0.0};
+  for (uint32_t k = gh_ptr[n]; k < gh_ptr[n + 1]; ++k) {
+    const double *p = partials + (size_t)gh_list[k] * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sum[c] += p[c];
+  }
+  double *o = ghost_out + (size_t)(gh_nodes[n] - (uint32_t)n_owned) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = sum[c];
+}
 __global__ void __launch_bounds__(256) k_brick_fix_pull(const BrickFixArgs F, const PullArgs P, const unsigned n_fix_blocks) {
   if (blockIdx.x < n_fix_blocks) brick_fix_body(F, blockIdx.x);
   else pull_body<1, 1>(P, blockIdx.x - n_fix_blocks);
@@ -76,16 +99,32 @@ __global__ void __launch_bounds__(256) k_brick_fix_pull(const BrickFixArgs F, co
 }  // namespace
 
 int launch_op_bricks(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
-                     const double *src_p, double *partials, double *slots_p, const EpiArgs &eu, const EpiArgs *ep) {
+                     const double *src_p, double *partials, double *slots_p, const EpiArgs &eu, const EpiArgs *ep, int phase) {
   const BrickTables &bk = L.bk;
   if (!bk.built || L.dim != 3) { set_error("launch_op_bricks: level has no brick tables"); return -1; }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB) { set_error("launch_op_bricks: epilogue not supported"); return -1; }
   if (ep && which != AGMG_OP_STOKES) { set_error("launch_op_bricks: pressure epilogue misuse"); return -1; }
   if (!brickq_supported(L, cd, which)) { set_error("launch_op_bricks: operator not supported on the brick path"); return -1; }
-  const int rc = launch_brickq(s, L, cd, which, src_u, src_p, partials, slots_p, eu);
-  if (rc) return rc;
-  const BrickFixArgs f{bk.fx_nodes, bk.fx_ptr, bk.fx_list, partials, bk.n_fix, eu};
+  if (phase != PH_ALL && ep) { set_error("launch_op_bricks: pressure epilogue on a distributed level"); return -1; }
+  if (phase != PH_OWNED) {
+    const int b0 = phase == PH_INTERFACE ? bk.n_interior : 0;
+    const int nb = phase == PH_INTERIOR ? bk.n_interior : bk.n_bricks - b0;
+    const int rc = launch_brickq(s, L, cd, which, src_u, src_p, partials, slots_p, eu, b0, nb);
+    if (rc) return rc;
+  }
+  if (phase == PH_INTERIOR) return 0;
+  if (phase == PH_GHOST || phase == PH_INTERFACE) {
+    if (bk.n_gh > 0) {
+      if (!L.xv.ghostbuf || L.xv.n_ghost <= 0) { set_error("launch_op_bricks: ghost nodes without an exchange buffer"); return -1; }
+      hipLaunchKernelGGL(k_brick_ghost, dim3((unsigned)((bk.n_gh + 255) / 256)), dim3(256), 0, s, bk.gh_nodes, bk.gh_ptr, bk.gh_list,
+                         partials, L.xv.ghostbuf, bk.n_gh, L.n_owned_v);
+      AGMG_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+  }
+  BrickFixArgs f{bk.fx_nodes, bk.fx_ptr, bk.fx_list, partials, bk.n_fix, eu, 0xFFFFFFFFu, nullptr};
+  if (L.xv.n_export > 0) { f.recv_base = (uint32_t)bk.n_partial_slots; f.recv = L.xv.expbuf; }
   const unsigned nf = (unsigned)((bk.n_fix + 255) / 256);
   if (!ep) {
     if (nf) hipLaunchKernelGGL(k_brick_fix, dim3(nf), dim3(256), 0, s, f);

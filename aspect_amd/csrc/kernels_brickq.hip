@@ -75,6 +75,7 @@ struct BqArgs {
   double *partials, *slots_p;
   double lambda;
   int Z, latn, npb, rows, cstride;
+  int brick0;                 // first brick of this launch (distributed levels: interior bricks, then interface bricks)
 };
 
 // 3-way select by the lane's component
@@ -100,7 +101,7 @@ k_brickq(const BqArgs B, const EpiArgs E) {
   const int c_lane = live ? cq : 0;
   const int ii_lane = 4 * (wave & 1) + (quad & 3), jj_lane = 4 * (wave >> 1) + (quad >> 2);
   const int cl_lane = ii_lane + 8 * jj_lane;
-  const int brick = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  const int brick = B.brick0 + (int)xcd_contiguous(blockIdx.x, gridDim.x);
   const uint32_t *const gn = B.gnode + (size_t)brick * B.latn;
   const size_t pbase = (size_t)brick * B.npb;
   const int nplanes_b = 2 * B.Z + 1;
@@ -562,8 +563,11 @@ int launch_brick_geo(hipStream_t s, const DeviceLevel &L, const CoeffData &cd) {
 }
 
 int launch_brickq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u, const double *src_p,
-                  double *partials, double *slots_p, const EpiArgs &eu) {
+                  double *partials, double *slots_p, const EpiArgs &eu, int brick0, int n_launch) {
   const BrickTables &bk = L.bk;
+  if (n_launch < 0) n_launch = bk.n_bricks - brick0;
+  if (brick0 < 0 || n_launch < 0 || brick0 + n_launch > bk.n_bricks) { set_error("launch_brickq: bad brick range"); return -1; }
+  if (n_launch == 0) return 0;
   const bool perq = cd.nqv > 1;
   const bool comp = (cd.is_compressible != 0 || cd.dilation) && which != AGMG_OP_BT;
   static unsigned long long *dbg_buf = nullptr;
@@ -571,8 +575,8 @@ int launch_brickq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int 
   if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)1 << 26);
 #endif
   const BqArgs b{dbg_buf, bk.gnode, bk.bcell, cd.brick_geo, src_u, src_p, L.cnpT, partials, slots_p, cd.lambda,
-                 bk.Z, bk.latn, bk.npb, cd.nqv + 4, L.cstride};
-  const dim3 grid(bk.n_bricks), block(BQ_T);
+                 bk.Z, bk.latn, bk.npb, cd.nqv + 4, L.cstride, brick0};
+  const dim3 grid(n_launch), block(BQ_T);
   if (comp) {
     if (perq) hipLaunchKernelGGL((k_brickq<KOP_A, true, true>), grid, block, 0, s, b, eu);
     else hipLaunchKernelGGL((k_brickq<KOP_A, true, false>), grid, block, 0, s, b, eu);

@@ -211,6 +211,13 @@ def main():
             fails.append("overlap although AGMG_NO_OVERLAP=1")
         if ranks.rank == 0:
             print(f"[dist] finest level: {n_int} interior + {n_ifc} interface blocks, {n_over} overlapped operator applications", flush=True)
+    if os.environ.get("AGMG_BRICKS") == "1":
+        # the levels that run the brick kernels on this rank (agmg_get_level_kernel_path)
+        on = [l for l in range(nl) if hip.kernel_path(l)[0] > 0]
+        if ranks.rank == 0:
+            print(f"[dist] brick levels {on}", flush=True)
+        if not on:
+            fails.append("AGMG_BRICKS=1 but no level runs the brick kernels")
     nfail = ranks.sum_over_ranks(float(len(fails)))
     for f in fails:
         print(f"[dist rank {ranks.rank}] FAIL {f}", flush=True)

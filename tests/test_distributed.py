@@ -100,3 +100,16 @@ def test_distributed_without_overlap_gives_the_same_result(monkeypatch):
     monkeypatch.setenv("AGMG_NO_OVERLAP", "1")
     out = _launch(2, [os.path.join("tests", "dist_worker.py"), "nsinker_r3", "gloo-dev", "all"], 29571)
     assert "[dist]" in out and "0 overlapped" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,case,wire", [(2, "box3d_r4_ranklocal", "gloo-dev"), (4, "box3d_r3", "gloo"), (2, "nsinker_r3", "gloo"),
+                                             (8, "box3d_r3_rep2", "gloo")])
+def test_distributed_brick_levels_match_serial_oracle(nproc, case, wire, monkeypatch):
+    """The quad-per-cell brick kernel on the levels of a distributed context (AGMG_BRICKS=1 puts every level that tiles
+    into 8^3 cubes on it; by default the levels of 512 cubes or more per rank, i.e. BASELINE configs[4]'s r7 cube per GPU):
+    ghost nodes are owned by no brick, their sums travel in the compress step, the fix-up of the owned rows adds the
+    received sums.  Operators, V-cycles, preconditioner and solve against the serial oracle as above."""
+    monkeypatch.setenv("AGMG_BRICKS", "1")
+    out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, wire, "all"], 29580 + nproc)
+    assert "[dist]" in out and "brick levels" in out
