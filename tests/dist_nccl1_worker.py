@@ -48,6 +48,17 @@ def main():
         np.linalg.norm(xa - xb) <= 1e-6 * np.linalg.norm(xa)
     print(f"[nccl1] native RCCL transport: iterations {rb.n_cheap_iterations} vs {ra.n_cheap_iterations}", flush=True)
     ok = ok and same
+    # the two coarsest levels marked as replicated: their dot products stay local, and the restriction onto the last of
+    # them ends in an ncclAllReduce of the whole coarse defect on the library stream (agmg_ctx::allreduce_vec)
+    loc2 = partition.LocalProblem(g, 0, 1)
+    for lev in loc2.hier.levels[:2]:
+        lev.replicated = True
+    rep = capi.Solver(capi.load(), loc2, transport=parallel.RcclTransport(ranks))
+    xc, rc_, _ = rep.solve()
+    same2 = ra.n_cheap_iterations == rc_.n_cheap_iterations and np.linalg.norm(xa - xc) <= 1e-6 * np.linalg.norm(xa)
+    print(f"[nccl1] native RCCL transport, replicated coarse levels: iterations {rc_.n_cheap_iterations} vs {ra.n_cheap_iterations}", flush=True)
+    ok = ok and same2
+    rep.close()
     plain.close()
     native.close()
     print(f"[nccl1] {'ok' if ok else 'FAIL'}", flush=True)
