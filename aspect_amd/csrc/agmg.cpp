@@ -343,7 +343,7 @@ struct agmg_ctx {
   bool use_blocks = true;
   bool use_ell = true;     // assembled rows for the Q1 mass operator (AGMG_NO_ELL=1: matrix-free cell kernel + pull)
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
-    return use_ell && !ldist(lv) && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
+    return use_ell && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
   }
   bool use_batched_setup = true;   // eigenvalue estimates of all levels in lock step (AGMG_NO_BATCHED_SETUP=1: one by one)
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
@@ -441,6 +441,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.gid_v); dfree(l.gid_p);
   dfree(l.ell_col); dfree(l.coeff.ell_val); dfree(l.coeff.brick_geo);
+  dfree(l.ell_xrow); dfree(l.ell_xptr); dfree(l.ell_xent);
   l = DeviceLevel();
 }
 
@@ -1179,6 +1180,12 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
     return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_OWNED);
   }
   CHECK(update_ghosts(lv.xp, x));
+  if (mass_ell(lv, cd)) {
+    // assembled rows of the rank's own cells: the ghost rows are the shares their owners still miss
+    CHECK(launch_mass_ell(stream, lv, cd, x, e, PH_GHOST));
+    CHECK(compress(lv.xp));
+    return launch_mass_ell(stream, lv, cd, x, e, PH_OWNED);
+  }
   CHECK(launch_mass_cells(stream, lv, cd, x, slots_p));
   CHECK(launch_pull_p(stream, lv, slots_p, 1, e, PH_GHOST));
   CHECK(compress(lv.xp));
@@ -2646,7 +2653,7 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
                         nn <= MS_MAX_NODES && max_val <= 8;
       // column structure of the assembled mass rows: the nodes of the cells around each node,
       // ascending; a patch with more than 3^dim nodes (irregular vertex) keeps the matrix-free path
-      if (!c->ldist(lv) && c->use_ell) {
+      if (c->use_ell) {
         const int W = NV;   // 3^dim
         const size_t npad = ((size_t)nn + 63) / 64 * 64;
         std::vector<uint32_t> col((size_t)W * npad);
@@ -2657,6 +2664,7 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
             int cnt = 0;
             bool ok_i = true;
             for (uint32_t k = ptr[i]; k < ptr[i + 1] && ok_i; ++k) {
+              if (list[k] >= (uint32_t)((size_t)nloc * cs)) continue;   // (an entry of the receive buffer)
               const size_t cell = list[k] % cs;
               for (int a = 0; a < nloc; ++a) {
                 const uint32_t node = cn[cell * nloc + a];
@@ -2682,6 +2690,17 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
           lv.ell_w = W;
           lv.ell_stride = (int)npad;
           lv.bytes_tables += col.size() * 4;
+          if (!snh.empty()) {   // received shares of the owned rows other ranks ghost: entry k of the receive buffer belongs to snh[k]
+            std::vector<int32_t> xrow(lv.n_owned_p, -1);
+            std::vector<uint32_t> xptr(1, 0), xent(snh.size());
+            for (uint32_t node : snh) if (xrow[node] < 0) { xrow[node] = (int32_t)xptr.size() - 1; xptr.push_back(0); }
+            for (uint32_t node : snh) ++xptr[xrow[node] + 1];
+            for (size_t k = 1; k < xptr.size(); ++k) xptr[k] += xptr[k - 1];
+            std::vector<uint32_t> xfill(xptr.begin(), xptr.end() - 1);
+            for (size_t k = 0; k < snh.size(); ++k) xent[xfill[xrow[snh[k]]]++] = (uint32_t)k;
+            CHECK(c->upload(&lv.ell_xrow, xrow)); CHECK(c->upload(&lv.ell_xptr, xptr)); CHECK(c->upload(&lv.ell_xent, xent));
+            lv.bytes_tables += (xrow.size() + xptr.size() + xent.size()) * 4;
+          }
         }
       }
     }
@@ -3037,7 +3056,7 @@ static int set_coefficients_on(agmg_ctx *c, DeviceLevel &lv, CoeffData &cd, bool
   if (cd.ell_stride != lv.ell_stride) { c->dfree(cd.ell_val); cd.ell_stride = 0; }
   // (not for the active-mesh coefficients: the solve only applies the level operators' mass
   // matrices; an active-mesh mass vmult keeps the matrix-free kernels)
-  if (lv.ell_col && c->use_ell && !c->ldist(lv) && level != AGMG_ACTIVE) {
+  if (lv.ell_col && c->use_ell && level != AGMG_ACTIVE) {
     if (!cd.ell_val) CHECK(c->dalloc(&cd.ell_val, (size_t)lv.ell_w * lv.ell_stride));
     cd.ell_stride = lv.ell_stride;
     CHECK(launch_mass_ell_assemble(c->stream, lv, cd));

@@ -190,6 +190,9 @@ struct DeviceLevel {
   // (unused entries point at the row's own node and carry the value 0); values live in CoeffData
   uint32_t *ell_col = nullptr;
   int ell_w = 0, ell_stride = 0;
+  // distributed levels: per owned pressure node its row in the CSR of received shares (-1: nobody ghosts the node)
+  int32_t *ell_xrow = nullptr;
+  uint32_t *ell_xptr = nullptr, *ell_xent = nullptr;
   size_t bytes_tables = 0, bytes_transfer = 0, bytes_constraints = 0;
   int n_dofs_v() const { return dim * n_nodes_v; }
   int n_dofs_p() const { return n_nodes_p; }
@@ -248,7 +251,9 @@ int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, cons
 // epilogue *ep (one rank: the velocity fix-up and the pressure pull share one launch).
 // assembled Q1 mass rows: cd.ell_val = rows of lambda^2 (1/eta) mass matrix (set-up), and dst = epilogue(M src)
 int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffData &cd);
-int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e);
+// phase (distributed levels): PH_GHOST = the ghost rows' raw sums into Exchange::ghostbuf, PH_OWNED = the owned rows with the
+// received shares added before the epilogue
+int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int phase = 0);
 
 // free-surface stabilisation faces of the active Stokes operator (matrix_free_operators.cc:294-333),
 // organised by node: every surface node lists the (face, local index) pairs that touch it

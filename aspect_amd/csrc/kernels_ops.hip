@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) k_mass_ell_assemble(const CellArgs A, con
   for (uint32_t k = M.ptr[n]; k < M.ptr[n + 1]; ++k) {
     const uint32_t ent = M.list[k];
     const int b = (int)(ent / cs);
+    if (b >= NP) continue;   // (distributed levels: an entry of the receive buffer, not a cell)
     const size_t cell = ent - (size_t)b * cs;
     double det = 1.0;
 #pragma unroll
@@ -176,11 +177,20 @@ struct EllMulArgs {
   const uint8_t *cmask;
   const double *src;
   EpiArgs e;
+  // distributed levels: rows [node0, node0 + n_nodes).  ghost_out != nullptr: the raw sums of the ghost rows (the
+  // shares of this rank's cells) go to ghost_out[row - node0] for the compress step; else the rows are owned rows and
+  // those another rank ghosts (xrow[n] >= 0) add the received shares recv[xent[k]], k in [xptr[xrow], xptr[xrow + 1])
+  int node0;
+  double *ghost_out;
+  const int32_t *xrow;
+  const uint32_t *xptr, *xent;
+  const double *recv;
 };
 template <int W>
 __global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= M.n_nodes) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M.n_nodes) return;
+  const int n = M.node0 + i;
   const size_t st = (size_t)M.stride;
   uint32_t col[W];
   double val[W];
@@ -189,6 +199,12 @@ __global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
   double sum = 0.0;
 #pragma unroll
   for (int k = 0; k < W; ++k) sum = fma(val[k], M.src[col[k]], sum);
+  if (M.ghost_out) { M.ghost_out[i] = sum; return; }
+  if (M.xrow) {
+    const int xr = M.xrow[n];
+    if (xr >= 0)
+      for (uint32_t k = M.xptr[xr]; k < M.xptr[xr + 1]; ++k) sum += M.recv[M.xent[k]];
+  }
   const bool con = M.cmask ? (M.cmask[n] & 1u) : false;
   double out;
   if (epi_value(M.e, (size_t)n, sum, con, out)) M.e.dst[n] = out;
@@ -1084,11 +1100,21 @@ int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffDat
   return 0;
 }
 
-int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e) {
+int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int phase) {
   if (!L.ell_col || !cd.ell_val || cd.ell_stride != L.ell_stride) { set_error("mass rows not assembled"); return -4; }
-  if (L.n_nodes_p <= 0) return 0;
-  const EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e};
-  const dim3 grid((L.n_nodes_p + 255) / 256), block(256);
+  EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (phase == PH_GHOST) {
+    m.node0 = L.n_owned_p; m.n_nodes = L.n_nodes_p - L.n_owned_p; m.ghost_out = L.xp.ghostbuf;
+    if (m.n_nodes > 0 && !m.ghost_out) { set_error("launch_mass_ell: ghost rows without an exchange buffer"); return -1; }
+  } else if (phase == PH_OWNED) {
+    m.n_nodes = L.n_owned_p;
+    if (L.xp.n_export > 0) {
+      if (!L.ell_xrow) { set_error("launch_mass_ell: level has no table of exported rows"); return -1; }
+      m.xrow = L.ell_xrow; m.xptr = L.ell_xptr; m.xent = L.ell_xent; m.recv = L.xp.expbuf;
+    }
+  } else if (phase != PH_ALL) { set_error("launch_mass_ell: bad phase"); return -1; }
+  if (m.n_nodes <= 0) return 0;
+  const dim3 grid((m.n_nodes + 255) / 256), block(256);
   if (L.dim == 3) hipLaunchKernelGGL((k_mass_ell<27>), grid, block, 0, s, m);
   else hipLaunchKernelGGL((k_mass_ell<9>), grid, block, 0, s, m);
   AGMG_HIP_CHECK(hipGetLastError());
