@@ -61,6 +61,7 @@ class LevelDesc(C.Structure):
         ("n_copy_v", C.c_int32), ("n_copy_p", C.c_int32),
         ("copy_active_v", c_u32p), ("copy_level_v", c_u32p), ("copy_active_p", c_u32p), ("copy_level_p", c_u32p),
         ("replicated", C.c_int32),
+        ("n_sym_neighbors_p", C.c_int32), ("sym_neighbor_rank_p", c_i32p), ("sym_offsets_p", c_i32p), ("sym_nodes_p", c_u32p),
     ]
 
 
@@ -294,6 +295,12 @@ class Solver:
             d.send_offsets_p, d.send_nodes_p, d.recv_offsets_p = _ptr(plan[3], C.c_int32), _ptr(plan[4], C.c_uint32), _ptr(plan[5], C.c_int32)
             d.global_nodes_v, d.global_nodes_p = _ptr(plan[6], C.c_uint32), _ptr(plan[7], C.c_uint32)
             keep += [nb] + plan
+            if getattr(lev, "sym_neighbors_p", None) is not None and len(lev.sym_neighbors_p):
+                sym = [np.ascontiguousarray(lev.sym_neighbors_p, dtype=np.int32), np.ascontiguousarray(lev.sym_offsets_p, dtype=np.int32),
+                       np.ascontiguousarray(lev.sym_nodes_p, dtype=np.uint32)]
+                d.n_sym_neighbors_p = sym[0].size
+                d.sym_neighbor_rank_p, d.sym_offsets_p, d.sym_nodes_p = _ptr(sym[0], C.c_int32), _ptr(sym[1], C.c_int32), _ptr(sym[2], C.c_uint32)
+                keep += sym
         if getattr(lev, "hanging_v", None) is not None:
             # hanging-node constraints of an adaptive mesh: (nodes, ptr, masters, weights) per space
             for name, (hn, hp, hm, hw) in (("v", lev.hanging_v), ("p", lev.hanging_p)):

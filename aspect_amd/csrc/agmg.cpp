@@ -345,6 +345,14 @@ struct agmg_ctx {
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
     return use_ell && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
   }
+  // one message round per application of the mass operator inside a smoother sequence (SymExchange; AGMG_NO_SYM=1:
+  // ghost import + compress, two rounds).  sym_now: the vectors of the running operator application carry valid ghost
+  // entries (set by the smoother around its sequence)
+  bool use_sym = true, sym_now = false;
+  std::vector<const double *> sym_rhs_valid;   // per level: the right-hand side whose ghost entries the pre-smoother made valid
+  int n_sym_applications = 0;     // (tests)
+  bool mass_sym(const DeviceLevel &lv, const CoeffData &cd) const { return use_sym && ldist(lv) && lv.sp.active() && mass_ell(lv, cd); }
+  int apply_mass_sym(const DeviceLevel &lv, const CoeffData &cd, const double *x, const EpiArgs &e);
   bool use_batched_setup = true;   // eigenvalue estimates of all levels in lock step (AGMG_NO_BATCHED_SETUP=1: one by one)
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
   // Chebyshev coefficient sequences of cheb_vmult / cheb_step as a program for the fused kernels
@@ -439,6 +447,8 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.bk.gnode); dfree(l.bk.bcell); dfree(l.bk.pidx); dfree(l.bk.fx_nodes); dfree(l.bk.fx_ptr); dfree(l.bk.fx_list);
   dfree(l.bk.gh_nodes); dfree(l.bk.gh_ptr); dfree(l.bk.gh_list);
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
+  dfree(l.sp.sh_nodes); dfree(l.sp.ptr); dfree(l.sp.pos); dfree(l.sp.split); dfree(l.sp.row);
+  dfree(l.sp.sendbuf); dfree(l.sp.recvbuf); dfree(l.sp.ypart);
   dfree(l.gid_v); dfree(l.gid_p);
   dfree(l.ell_col); dfree(l.coeff.ell_val); dfree(l.coeff.brick_geo);
   dfree(l.ell_xrow); dfree(l.ell_xptr); dfree(l.ell_xent);
@@ -1179,6 +1189,7 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
     CHECK(compress(lv.xv));
     return launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_OWNED);
   }
+  if (sym_now && mass_sym(lv, cd)) return apply_mass_sym(lv, cd, x, e);
   CHECK(update_ghosts(lv.xp, x));
   if (mass_ell(lv, cd)) {
     // assembled rows of the rank's own cells: the ghost rows are the shares their owners still miss
@@ -1190,6 +1201,23 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
   CHECK(launch_pull_p(stream, lv, slots_p, 1, e, PH_GHOST));
   CHECK(compress(lv.xp));
   return launch_pull_p(stream, lv, slots_p, 1, e, PH_OWNED);
+}
+
+// Mass operator of a distributed level in ONE message round (SymExchange): the source carries valid ghost entries (the
+// smoother keeps them valid: every rank that holds a row applies the update to its own copy), every rank computes the
+// shares of the rows others hold too, sends them to all of those, adds what it receives in rank order and runs the
+// epilogue on EVERY local row, owned or ghost.  b, dinv and xold of the epilogue need valid ghost entries as well.
+int agmg_ctx::apply_mass_sym(const DeviceLevel &lv, const CoeffData &cd, const double *x, const EpiArgs &e) {
+  const SymExchange &sx = lv.sp;
+  CHECK(launch_mass_ell_sym(stream, lv, cd, x, e, 0));
+  std::vector<Msg> m;
+  for (size_t k = 0; k < sx.nbr.size(); ++k) {
+    const int64_t n = sx.off[k + 1] - sx.off[k];
+    m.push_back({sx.nbr[k], sx.sendbuf + sx.off[k], n, sx.recvbuf + sx.off[k], n});
+  }
+  CHECK(exchange(m));
+  ++n_sym_applications;
+  return launch_mass_ell_sym(stream, lv, cd, x, e, 1);
 }
 
 // one-rank level operators on given tables: which01 0 = A block, 1 = mass
@@ -1473,8 +1501,23 @@ int agmg_ctx::smooth_A_seq(int l, bool zero_start, const double *rhs, double *re
 }
 
 // mg::SmootherRelaxation(steps): apply = vmult + (steps-1) step; smooth = steps x step
+namespace {
+struct FlagGuard {   // sets a flag for the life of a scope
+  bool &f, was;
+  FlagGuard(bool &flag, bool v) : f(flag), was(flag) { f = v; }
+  ~FlagGuard() { f = was; }
+};
+}  // namespace
+
 int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  const bool sym = which == 1 && mass_sym(L[l], L[l].coeff);
+  if (sym) {   // (the iterate starts from dinv * rhs on every local entry)
+    CHECK(update_ghosts(L[l].xp, rhs));
+    if ((int)sym_rhs_valid.size() != nl()) sym_rhs_valid.assign(nl(), nullptr);
+    sym_rhs_valid[l] = rhs;
+  }
+  FlagGuard guard(sym_now, sym);
   if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
     SmootherProgram p;
     program_vmult(sm[1][l], p);
@@ -1488,6 +1531,12 @@ int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
 }
 int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
+  const bool sym = which == 1 && mass_sym(L[l], L[l].coeff);
+  if (sym) {   // the right-hand side and the iterate (coarse-grid correction added) with valid ghost entries
+    if ((int)sym_rhs_valid.size() != nl() || sym_rhs_valid[l] != rhs) CHECK(update_ghosts(L[l].xp, rhs));
+    CHECK(update_ghosts(L[l].xp, mg_sol[1][l]));
+  }
+  FlagGuard guard(sym_now, sym);
   if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
     SmootherProgram p;
     for (int i = 0; i < steps; ++i) program_step(sm[1][l], p);
@@ -1598,6 +1647,8 @@ int agmg_ctx::level_v_step(int which, int l) {
   {  // t = defect - A solution
     EpiArgs e;
     e.epi = EPI_RESID; e.dst = mg_t[which][l]; e.b = mg_def[which][l];
+    // (behind the symmetric smoother sequence the iterate and the defect carry valid ghost entries: one round here too)
+    FlagGuard guard(sym_now, which == 1 && mass_sym(F, F.coeff));
     CHECK(apply_level(which, l, F.coeff, mg_sol[which][l], e));
   }
   }
@@ -2459,6 +2510,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (const char *e = getenv("AGMG_BRICK_STACK")) c->brick_stack_override = atoi(e);
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_NO_SYM")) c->use_sym = atoi(e) == 0;
   if (const char *e = getenv("AGMG_GRAPHS")) c->use_graphs = atoi(e) != 0;
   if (const char *e = getenv("AGMG_NO_BATCHED_SETUP")) c->use_batched_setup = atoi(e) == 0;
   c->L.resize(opt->n_levels);
@@ -2605,6 +2657,43 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
       CHECK(c->dalloc(&x.ghostbuf, (size_t)x.n_ghost * x.nc));
       lv.bytes_tables += snh.size() * 4;
     }
+  }
+  if (has_plan && d->n_sym_neighbors_p > 0 && !lv.replicated) {
+    // symmetric exchange plan of the pressure nodes (SymExchange)
+    const int nn_ = d->n_sym_neighbors_p;
+    if (!d->sym_neighbor_rank_p || !d->sym_offsets_p || !d->sym_nodes_p || d->sym_offsets_p[0] != 0) { set_error("incomplete symmetric exchange plan"); return -1; }
+    SymExchange &sx = lv.sp;
+    sx.nbr.assign(d->sym_neighbor_rank_p, d->sym_neighbor_rank_p + nn_);
+    sx.off.assign(d->sym_offsets_p, d->sym_offsets_p + nn_ + 1);
+    for (int k = 0; k < nn_; ++k) {
+      if (sx.nbr[k] < 0 || sx.nbr[k] >= c->opt.world_size || sx.nbr[k] == c->opt.rank || (k > 0 && sx.nbr[k] <= sx.nbr[k - 1]) || sx.off[k + 1] < sx.off[k]) {
+        set_error("symmetric exchange plan: neighbour ranks ascending, offsets non-decreasing"); return -1;
+      }
+    }
+    sx.n_sym = sx.off[nn_];
+    std::vector<int32_t> row(d->n_nodes_p, -1);
+    std::vector<uint32_t> sh_nodes, cnt;
+    for (int i = 0; i < sx.n_sym; ++i) {
+      const uint32_t node = d->sym_nodes_p[i];
+      if ((int)node >= d->n_nodes_p) { set_error("symmetric exchange plan: node out of range"); return -1; }
+      if (row[node] < 0) { row[node] = (int32_t)sh_nodes.size(); sh_nodes.push_back(node); cnt.push_back(0); }
+      ++cnt[row[node]];
+    }
+    sx.n_sh = (int)sh_nodes.size();
+    std::vector<uint32_t> ptr(sx.n_sh + 1, 0), pos(sx.n_sym);
+    for (int r = 0; r < sx.n_sh; ++r) ptr[r + 1] = ptr[r] + cnt[r];
+    std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+    std::vector<uint8_t> split(sx.n_sh, 0);
+    for (int k = 0; k < nn_; ++k)      // neighbours ascending: the positions of a node come out in rank order
+      for (int i = sx.off[k]; i < sx.off[k + 1]; ++i) {
+        const int r = row[d->sym_nodes_p[i]];
+        pos[fill[r]++] = (uint32_t)i;
+        if (sx.nbr[k] < c->opt.rank) ++split[r];
+      }
+    CHECK(c->upload(&sx.sh_nodes, sh_nodes)); CHECK(c->upload(&sx.ptr, ptr)); CHECK(c->upload(&sx.pos, pos));
+    CHECK(c->upload(&sx.split, split)); CHECK(c->upload(&sx.row, row));
+    CHECK(c->dalloc(&sx.sendbuf, (size_t)sx.n_sym)); CHECK(c->dalloc(&sx.recvbuf, (size_t)sx.n_sym)); CHECK(c->dalloc(&sx.ypart, (size_t)sx.n_sh));
+    lv.bytes_tables += (sh_nodes.size() + ptr.size() + pos.size() + row.size()) * 4 + split.size();
   }
   for (int vel = 0; vel < 2; ++vel) {
     const uint32_t *gn = vel ? d->global_nodes_v : d->global_nodes_p;
@@ -3181,6 +3270,8 @@ int agmg_compute_diagonals(agmg_ctx *c) {
       CHECK(c->exchange(m));
       CHECK(launch_pull_v(c->stream, l, c->slots_u, eA, PH_OWNED));
       CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, eM, PH_OWNED));
+      // (the symmetric smoother sequences apply the update to the ghost copies too: they read the diagonal there)
+      if (l.sp.active()) CHECK(c->update_ghosts(l.xp, l.inv_diag_M));
     }
   }
   CHECK(c->sync());

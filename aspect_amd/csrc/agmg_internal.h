@@ -150,6 +150,21 @@ struct Exchange {
   bool active() const { return !nbr.empty(); }
 };
 
+// Symmetric exchange of the pressure nodes of a distributed level (agmg_level_desc::sym_*): every rank that touches a
+// node sends its share of a sum to every other rank that touches it; entry i of the message to neighbour k and entry i
+// of the message from it belong to the same node, so one position table serves the send and the receive buffer.
+struct SymExchange {
+  std::vector<int> nbr, off;       // ascending ranks; [n_nbr + 1] offsets into the buffers
+  int n_sym = 0, n_sh = 0;         // buffer entries; distinct shared local nodes
+  uint32_t *sh_nodes = nullptr;    // [n_sh] local node
+  uint32_t *ptr = nullptr;         // [n_sh + 1] into pos
+  uint32_t *pos = nullptr;         // buffer positions of a shared node, ascending neighbour rank
+  uint8_t *split = nullptr;        // [n_sh] how many of them belong to ranks below this one (rank-ordered sums)
+  int32_t *row = nullptr;          // [n_nodes] index among the shared nodes, or -1
+  double *sendbuf = nullptr, *recvbuf = nullptr, *ypart = nullptr;   // [n_sym], [n_sym], [n_sh]
+  bool active() const { return !nbr.empty(); }
+};
+
 struct DeviceLevel {
   bool set = false;
   int dim = 3;
@@ -157,6 +172,7 @@ struct DeviceLevel {
   int n_owned_v = 0, n_owned_p = 0;  // owned nodes come first; == n_nodes_* on one rank
   bool replicated = false;           // distributed context: every rank holds this level whole (agmg_level_desc::replicated)
   Exchange xv, xp;
+  SymExchange sp;                  // pressure nodes, optional
   uint32_t *gid_v = nullptr, *gid_p = nullptr;  // global node index of each local node (nullptr: identity)
   int cstride = 0;                 // padded cell count (SoA row stride)
   // SoA tables: [local index][cstride]
@@ -254,6 +270,10 @@ int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffDat
 // phase (distributed levels): PH_GHOST = the ghost rows' raw sums into Exchange::ghostbuf, PH_OWNED = the owned rows with the
 // received shares added before the epilogue
 int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int phase = 0);
+// one message round per application (SymExchange): part 0 = the shares of the shared rows into the send buffer, part 1
+// (after the exchange) = every local row, owned or ghost, with the epilogue; the shares of a shared row are added in
+// rank order, so every rank that holds the row computes the same sum
+int launch_mass_ell_sym(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int part);
 
 // free-surface stabilisation faces of the active Stokes operator (matrix_free_operators.cc:294-333),
 // organised by node: every surface node lists the (face, local index) pairs that touch it

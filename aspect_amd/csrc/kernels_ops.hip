@@ -185,12 +185,27 @@ struct EllMulArgs {
   const int32_t *xrow;
   const uint32_t *xptr, *xent;
   const double *recv;
+  // symmetric exchange (SymExchange): srow != nullptr: a shared row takes its own share from ypart and the others'
+  // from the receive buffer, in rank order
+  const int32_t *srow;
+  const uint32_t *sptr, *spos;
+  const uint8_t *ssplit;
+  const double *ypart, *srecv;
 };
+struct EllSymArgs {
+  const uint32_t *col;
+  const double *val;
+  int n_sh, stride;
+  const double *src;
+  const uint32_t *sh_nodes, *sptr, *spos;
+  double *ypart, *sendbuf;
+};
+// shares of the rows other ranks hold too: into ypart, and into every message that carries the row
 template <int W>
-__global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= M.n_nodes) return;
-  const int n = M.node0 + i;
+__global__ void __launch_bounds__(256) k_mass_ell_sym_a(const EllSymArgs M) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= M.n_sh) return;
+  const uint32_t n = M.sh_nodes[s];
   const size_t st = (size_t)M.stride;
   uint32_t col[W];
   double val[W];
@@ -199,6 +214,33 @@ __global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
   double sum = 0.0;
 #pragma unroll
   for (int k = 0; k < W; ++k) sum = fma(val[k], M.src[col[k]], sum);
+  M.ypart[s] = sum;
+  for (uint32_t k = M.sptr[s]; k < M.sptr[s + 1]; ++k) M.sendbuf[M.spos[k]] = sum;
+}
+template <int W>
+__global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M.n_nodes) return;
+  const int n = M.node0 + i;
+  const size_t st = (size_t)M.stride;
+  const int sr = M.srow ? M.srow[n] : -1;
+  double sum = 0.0;
+  if (sr >= 0) {
+    const uint32_t s0 = M.sptr[sr], s1 = M.sptr[sr + 1], mine = s0 + M.ssplit[sr];
+    const double own = M.ypart[sr];
+    for (uint32_t k = s0; k < s1; ++k) {
+      if (k == mine) sum += own;
+      sum += M.srecv[M.spos[k]];
+    }
+    if (mine == s1) sum += own;
+  } else {
+    uint32_t col[W];
+    double val[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { col[k] = M.col[k * st + n]; val[k] = M.val[k * st + n]; }
+#pragma unroll
+    for (int k = 0; k < W; ++k) sum = fma(val[k], M.src[col[k]], sum);
+  }
   if (M.ghost_out) { M.ghost_out[i] = sum; return; }
   if (M.xrow) {
     const int xr = M.xrow[n];
@@ -1102,7 +1144,8 @@ int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffDat
 
 int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int phase) {
   if (!L.ell_col || !cd.ell_val || cd.ell_stride != L.ell_stride) { set_error("mass rows not assembled"); return -4; }
-  EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (phase == PH_GHOST) {
     m.node0 = L.n_owned_p; m.n_nodes = L.n_nodes_p - L.n_owned_p; m.ghost_out = L.xp.ghostbuf;
     if (m.n_nodes > 0 && !m.ghost_out) { set_error("launch_mass_ell: ghost rows without an exchange buffer"); return -1; }
@@ -1117,6 +1160,28 @@ int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, co
   const dim3 grid((m.n_nodes + 255) / 256), block(256);
   if (L.dim == 3) hipLaunchKernelGGL((k_mass_ell<27>), grid, block, 0, s, m);
   else hipLaunchKernelGGL((k_mass_ell<9>), grid, block, 0, s, m);
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_mass_ell_sym(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int part) {
+  if (!L.ell_col || !cd.ell_val || cd.ell_stride != L.ell_stride) { set_error("mass rows not assembled"); return -4; }
+  const SymExchange &x = L.sp;
+  if (!x.active() || !x.row) { set_error("launch_mass_ell_sym: level has no symmetric exchange plan"); return -1; }
+  if (part == 0) {
+    if (x.n_sh <= 0) return 0;
+    const EllSymArgs a{L.ell_col, cd.ell_val, x.n_sh, L.ell_stride, src_p, x.sh_nodes, x.ptr, x.pos, x.ypart, x.sendbuf};
+    const dim3 grid((x.n_sh + 255) / 256), block(256);
+    if (L.dim == 3) hipLaunchKernelGGL((k_mass_ell_sym_a<27>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_mass_ell_sym_a<9>), grid, block, 0, s, a);
+  } else {
+    if (L.n_nodes_p <= 0) return 0;
+    const EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       x.row, x.ptr, x.pos, x.split, x.ypart, x.recvbuf};
+    const dim3 grid((L.n_nodes_p + 255) / 256), block(256);
+    if (L.dim == 3) hipLaunchKernelGGL((k_mass_ell<27>), grid, block, 0, s, m);
+    else hipLaunchKernelGGL((k_mass_ell<9>), grid, block, 0, s, m);
+  }
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -68,6 +68,8 @@ class _Space:
         g2l = np.full(n_nodes, -1, dtype=np.int64)
         g2l[self.l2g] = np.arange(self.l2g.size)
         self.g2l = g2l
+        self.touch_local = touch[self.l2g]
+        self.rank, self.size = rank, size
         # ranks ghosting my owned nodes
         self.export = {}
         otouch = touch[owned]
@@ -78,6 +80,23 @@ class _Space:
             if sel.any():
                 self.export[k] = np.flatnonzero(sel)          # local (owned) indices, ascending global
         self.neighbors = set(self.export) | set(int(o) for o in np.unique(self.ghost_owner))
+
+    def sym_plan(self):
+        """The symmetric exchange plan (agmg_level_desc::sym_*): per rank that touches a node of mine, ascending, my
+        local nodes it touches too, ordered by global index -- both sides list the shared nodes in the same order, so
+        entry i of my message to rank k and entry i of its message to me belong to the same node."""
+        nbrs, off, nodes = [], [0], []
+        for k in range(self.size):
+            if k == self.rank:
+                continue
+            idx = np.flatnonzero(((self.touch_local >> np.uint64(k)) & np.uint64(1)) == 1)
+            if idx.size:
+                idx = idx[np.argsort(self.l2g[idx], kind="stable")]
+                nbrs.append(k)
+                nodes.append(idx)
+                off.append(off[-1] + idx.size)
+        return (np.asarray(nbrs, dtype=np.int32), np.asarray(off, dtype=np.int32),
+                (np.concatenate(nodes) if nodes else np.zeros(0)).astype(np.uint32))
 
     def plan(self, neighbors):
         send_off, send_nodes, recv_off = [0], [], []
@@ -156,6 +175,7 @@ class LocalLevel(_LocalVectors):
         self.neighbors = sorted(self.v.neighbors | self.p.neighbors)
         self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
         self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
+        self.sym_neighbors_p, self.sym_offsets_p, self.sym_nodes_p = self.p.sym_plan()
         self.global_nodes_v = self.v.l2g.astype(np.uint32)
         self.global_nodes_p = self.p.l2g.astype(np.uint32)
         self.n_global_nodes_v, self.n_global_nodes_p = glev.n_nodes_v, glev.n_nodes_p
@@ -289,6 +309,8 @@ class _ClosedFormSpace:
         pos2loc[order] = np.arange(uniq.size)
         self.cell_nodes = pos2loc[inv].reshape(gid.shape).astype(np.uint32)
         self.lattice = np.stack([x[order] for x in X], axis=1)        # lattice coordinates of the local nodes
+        self.touch_local = touch[order]
+        self.rank, self.size = rank, size
         self.export = {}
         otouch = touch[owned]
         for k in range(size):
@@ -300,6 +322,7 @@ class _ClosedFormSpace:
         self.neighbors = set(self.export) | set(int(o) for o in np.unique(self.ghost_owner))
 
     plan = _Space.plan
+    sym_plan = _Space.sym_plan
 
 
 class RankLocalBoxLevel(_LocalVectors):
@@ -363,6 +386,7 @@ class RankLocalBoxLevel(_LocalVectors):
         self.neighbors = sorted(self.v.neighbors | self.p.neighbors)
         self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
         self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
+        self.sym_neighbors_p, self.sym_offsets_p, self.sym_nodes_p = self.p.sym_plan()
         self.global_nodes_v = self.v.l2g.astype(np.uint32)
         self.global_nodes_p = self.p.l2g.astype(np.uint32)
         if parent_is_replicated and true_size > 1:

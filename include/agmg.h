@@ -190,6 +190,18 @@ typedef struct agmg_level_desc {
    * levels 0..k for some k; the finest level is never replicated.  (No counterpart in the reference: deal.II
    * partitions every level.) */
   int32_t replicated;
+  /* Optional symmetric exchange plan of the Q1 pressure nodes (distributed levels; no counterpart in deal.II, whose
+   * vectors know owner -> ghost and ghost -> owner only): per rank that touches a node of this rank, in ascending rank
+   * order, this rank's local nodes (owned or ghost) it touches too, ordered by global index, so that both sides list
+   * the shared nodes in the same order.  With it the Chebyshev smoother of the Schur-complement mass operator needs ONE
+   * message round per operator application instead of two (ghost import + compress): every rank that touches a node
+   * receives the shares of all the others, adds them in rank order and applies the smoother update to its own copy of
+   * the row, so the ghost copies of the iterate never go stale inside a smoother sequence.  n_sym_neighbors_p == 0:
+   * not given, two rounds per application as in the reference. */
+  int32_t n_sym_neighbors_p;
+  const int32_t *sym_neighbor_rank_p;   /* [n_sym_neighbors_p], ascending */
+  const int32_t *sym_offsets_p;         /* [n_sym_neighbors_p + 1] into sym_nodes_p */
+  const uint32_t *sym_nodes_p;          /* local node indices */
 } agmg_level_desc;
 
 /* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */

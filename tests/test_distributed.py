@@ -113,3 +113,12 @@ def test_distributed_brick_levels_match_serial_oracle(nproc, case, wire, monkeyp
     monkeypatch.setenv("AGMG_BRICKS", "1")
     out = _launch(nproc, [os.path.join("tests", "dist_worker.py"), case, wire, "all"], 29580 + nproc)
     assert "[dist]" in out and "brick levels" in out
+
+
+@pytest.mark.gpu
+def test_distributed_two_round_mass_smoother_gives_the_same_result(monkeypatch):
+    """AGMG_NO_SYM=1: the mass operator of the Schur smoother with ghost import + compress per application (the
+    reference's two rounds) instead of the symmetric exchange (one round); both against the serial oracle."""
+    monkeypatch.setenv("AGMG_NO_SYM", "1")
+    out = _launch(4, [os.path.join("tests", "dist_worker.py"), "box3d_r3_rep2", "gloo-dev", "all"], 29591)
+    assert "[dist]" in out
