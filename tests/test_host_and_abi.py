@@ -237,3 +237,38 @@ def test_replicated_coarse_levels_of_the_host_partitions(averaging):
             if l == k:
                 assert np.array_equal(la.parent_cell, lb.parent_cell) and np.array_equal(la.child_index, lb.child_index)
             assert np.array_equal(a.eta_levels[l], b.eta_levels[l]), (rank, l)
+
+
+def test_symmetric_exchange_plans_agree_between_ranks():
+    """agmg_level_desc::sym_*: every pair of ranks that touch a common pressure node list their shared nodes in the same
+    order (ascending global index), neighbours ascending by rank, on every level; the rank-local set-up gives the same
+    plan as the partition of the global mesh; a rank's plan covers exactly its ghost nodes and its exported nodes."""
+    from aspect_amd import partition
+    size, reps = 8, [2, 2, 2]
+
+    def case():
+        c = cases.nsinker_box(2, n_sinkers=4, ratio=1e4)
+        c.reps, c.extents = reps, [float(x) for x in reps]
+        return c
+
+    g = case().build()
+    loc = [partition.LocalProblem(g, r, size) for r in range(size)]
+    for l in range(g.hier.n_levels):
+        L = [p.hier.levels[l] for p in loc]
+        for a in range(size):
+            nb = list(L[a].sym_neighbors_p)
+            assert nb == sorted(nb) and a not in nb
+            shared = set()
+            for i, k in enumerate(nb):
+                mine = L[a].sym_nodes_p[L[a].sym_offsets_p[i]:L[a].sym_offsets_p[i + 1]]
+                j = list(L[k].sym_neighbors_p).index(a)
+                theirs = L[k].sym_nodes_p[L[k].sym_offsets_p[j]:L[k].sym_offsets_p[j + 1]]
+                ga, gb = L[a].p.l2g[mine], L[k].p.l2g[theirs]
+                assert np.array_equal(ga, gb) and np.all(np.diff(ga) > 0)
+                shared |= set(int(x) for x in mine)
+            exported = set(int(x) for x in L[a].send_nodes_p)
+            ghosts = set(range(L[a].n_owned_nodes_p, L[a].n_nodes_p))
+            assert shared == exported | ghosts
+            b = partition.RankLocalProblem(case(), a, size).hier.levels[l]
+            for key in ("sym_neighbors_p", "sym_offsets_p", "sym_nodes_p"):
+                assert np.array_equal(getattr(L[a], key), getattr(b, key)), (l, a, key)
