@@ -3347,7 +3347,7 @@ int agmg_vmult_device_noalloc(agmg_ctx *c, int which, int level, double *dst, co
   if (c->has_hanging()) { set_error("agmg_vmult_device_noalloc: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
   if (!dst || !src) { set_error("null vector"); return -1; }
   if (c->dist()) { set_error("agmg_vmult_device_noalloc: one-rank contexts only (the ghost exchange stages through buffers it allocates)"); return -2; }
-  if (c->ad.on) { set_error("agmg_vmult_device_noalloc: not in adaptive contexts (their constraint handling stages through host vectors)"); return -2; }
+  if (c->ad.on) { set_error("agmg_vmult_device_noalloc: not in adaptive contexts (the resolved source vector lives in a buffer the context allocates)"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
@@ -3705,12 +3705,10 @@ int agmg_solve(agmg_ctx *c, const double *rhs_h, double *x_h, int newton, agmg_s
 int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *seconds_per_vmult) {
   if (!c || n_repeat < 1 || !seconds_per_vmult) { set_error("bad argument"); return -1; }
   if (c->has_hanging()) { set_error("agmg_bench_vmult: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
-  if (c->ad.on && level == AGMG_ACTIVE) { set_error("agmg_bench_vmult: the active operators of adaptive contexts stage through the host; nothing to time yet"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   size_t n;
   CHECK(vmult_sizes(c, which, level, &n));
-  const int l = level == AGMG_ACTIVE ? c->nl() - 1 : level;
-  const DeviceLevel &lv = c->L[l];
+  const DeviceLevel &lv = level == AGMG_ACTIVE ? c->act() : c->L[level];
   double *src, *dst;
   CHECK(c->dalloc(&src, n)); CHECK(c->dalloc(&dst, n));
   {
@@ -3745,7 +3743,6 @@ int agmg_bench_vmult(agmg_ctx *c, int which, int level, int n_repeat, double *se
 int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
   if (!c || !seconds || n_repeat < 1) { set_error("bad argument"); return -1; }
   if (c->has_hanging()) { set_error("agmg_execute_solver_timings: the context holds hanging-node constraints; only agmg_vmult resolves them yet (SURVEY.md 8 f1, first slice)"); return -2; }
-  if (c->ad.on) { set_error("agmg_execute_solver_timings: the active operators of adaptive contexts stage through the host; nothing to time yet"); return -2; }
   AGMG_HIP_CHECK(hipSetDevice(c->opt.device));
   {
     CHECK(c->sync());
@@ -3754,7 +3751,7 @@ int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
     CHECK(c->sync());
     seconds[5] = now_s() - t0;
   }
-  const DeviceLevel &lv = c->fin();
+  const DeviceLevel &lv = c->act();
   const size_t nu = lv.n_dofs_v(), np = lv.n_dofs_p(), n = nu + np;
   double *src, *dst;
   CHECK(c->get_vec(5, &src)); CHECK(c->get_vec(6, &dst));
@@ -3779,7 +3776,7 @@ int agmg_execute_solver_timings(agmg_ctx *c, int n_repeat, double seconds[6]) {
   CHECK(timeit([&] { return c->precondition(false, dst, src, nullptr); }, &seconds[1]));
   CHECK(timeit([&] { return c->vcycle(0, dst, src); }, &seconds[2]));
   CHECK(timeit([&] { return c->vcycle(1, dst + nu, src + nu); }, &seconds[3]));
-  CHECK(timeit([&] { return c->apply_level(0, c->nl() - 1, c->active_coeff(), src, e); }, &seconds[4]));
+  CHECK(timeit([&] { return c->ad.on ? c->active_apply(AGMG_OP_A, dst, src, nullptr) : c->apply_level(0, c->nl() - 1, c->active_coeff(), src, e); }, &seconds[4]));
   return 0;
 }
 

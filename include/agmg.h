@@ -160,9 +160,8 @@ typedef struct agmg_level_desc {
    * node set runs its operator with those rows as identity rows (MatrixFreeOperators::Base) and the
    * interface operators (vmult_interface_down / _up, set_edge_matrices :1045, 1053) in the V-cycle.
    * One rank.  The constraints (resolve / transpose / identity rows) and the level copies are index
-   * kernels around the device operators (kernels_vec.hip); agmg_rhs_correction, free-surface faces,
-   * agmg_bench_vmult(AGMG_ACTIVE), agmg_execute_solver_timings and agmg_vmult_device_noalloc return -2
-   * in adaptive contexts. */
+   * kernels around the device operators (kernels_vec.hip); agmg_rhs_correction, free-surface faces and
+   * agmg_vmult_device_noalloc return -2 in adaptive contexts. */
   int32_t n_hanging_v, n_hanging_p;
   const uint32_t *hanging_nodes_v; const int32_t *hanging_ptr_v; const uint32_t *hanging_master_v; const double *hanging_weight_v;
   const uint32_t *hanging_nodes_p; const int32_t *hanging_ptr_p; const uint32_t *hanging_master_p; const double *hanging_weight_p;

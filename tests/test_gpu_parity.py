@@ -1106,5 +1106,9 @@ def test_local_smoothing_on_adaptive_meshes(n_second, hip_lib, oracle_lib):
         nu = m.n_dofs_v
         assert relerr(xg[:nu], xo[:nu]) < 1e-9 and relerr(xg[nu:], xo[nu:]) < 1e-9
         assert np.abs(m.distribute_v(xg[:nu]) - xg[:nu]).max() <= 1e-12 * np.abs(xg[:nu]).max()
+        # the reference's timing sections and the vmult timer run on the device in adaptive contexts too
+        sec = g.solver_timings(2)
+        assert all(v > 0 for v in sec.values()), sec
+        assert g.bench_vmult(capi.OP_A, capi.ACTIVE, 3) > 0 and g.bench_vmult(capi.OP_STOKES, capi.ACTIVE, 3) > 0
     finally:
         g.close(); o.close()
