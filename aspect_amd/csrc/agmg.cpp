@@ -1364,22 +1364,21 @@ int agmg_ctx::stokes_apply(const double *src, const EpiArgs &eu_in, double *dst)
     CHECK(add_update(m, lv.xp, const_cast<double *>(src) + nu, 1));
     return exchange(m);
   };
+  // (the pressure rows of a phase ride in the launch of the velocity fix-up of that phase)
   if (can_overlap(lv, eu, active_coeff(), AGMG_OP_STOKES)) {
     CHECK(begin_import(import));
     CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_INTERIOR));
     CHECK(end_import());
-    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_INTERFACE));
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_INTERFACE, &ep));
   } else {
     CHECK(import());
-    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_GHOST));
+    CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_GHOST, &ep));
   }
-  CHECK(launch_pull_p(stream, lv, slots_p, 1, ep, PH_GHOST));
   m.clear();
   add_compress(m, lv.xv, lv.xv.nc);
   add_compress(m, lv.xp, 1);
   CHECK(exchange(m));
-  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_OWNED));
-  CHECK(launch_pull_p(stream, lv, slots_p, 1, ep, PH_OWNED));
+  CHECK(launch_op(stream, lv, active_coeff(), AGMG_OP_STOKES, src, src + nu, slots_u, slots_p, eu, use_blocks, PH_OWNED, &ep));
   if (!faces.global_active) return 0;
   // boundary-face loop (matrix_free_operators.cc:343-353): the sums of the local faces go to the owned
   // rows directly; those of ghost rows travel to their owners in one more compress step

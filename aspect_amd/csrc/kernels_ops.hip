@@ -1298,8 +1298,11 @@ int launch_op_seq(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, cons
 int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int which, const double *src_u,
               const double *src_p, double *slots_u, double *slots_p, const EpiArgs &eu, bool use_blocks, int phase,
               const EpiArgs *ep) {
-  // ep (Stokes, PH_ALL only): also finish the pressure rows (pull of slots_p with epilogue *ep)
-  if (ep && (which != AGMG_OP_STOKES || phase != PH_ALL)) { set_error("launch_op: pressure epilogue misuse"); return -1; }
+  // ep (Stokes): also finish the pressure rows (pull of slots_p with epilogue *ep) -- all of them (PH_ALL), the ghost rows
+  // into the compress buffer (PH_GHOST / PH_INTERFACE) or the owned rows with the received sums (PH_OWNED); on the block
+  // path the velocity fix-up and the pressure pull of a phase share one launch
+  if (ep && (which != AGMG_OP_STOKES || phase == PH_INTERIOR)) { set_error("launch_op: pressure epilogue misuse"); return -1; }
+  const int pphase = phase == PH_INTERFACE ? PH_GHOST : phase;
   // (the Newton-derivative variant of the Stokes cell kernel exists on the slot path only: it runs
   // once per outer Krylov iteration)
   if (!use_blocks || !L.bt.built || (eu.epi != EPI_STORE && eu.epi != EPI_RESID && eu.epi != EPI_CHEB) ||
@@ -1313,20 +1316,30 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
     }
     const int rc = launch_pull_v(s, L, slots_u, eu, phase);
     if (rc || !ep) return rc;
-    return launch_pull_p(s, L, slots_p, 1, *ep, PH_ALL);
+    return launch_pull_p(s, L, slots_p, 1, *ep, pphase);
   }
   if (!cd.set) { set_error("coefficients not set for this level"); return -4; }
   if (L.n_cells <= 0) return 0;
   const BlockTables &bt = L.bt;
   // fix-up over the shared nodes of one phase: ghosts -> Exchange::ghostbuf, owned -> dst (+ received sums)
   auto fix = [&](int i0, int n_range, bool ghost) -> int {
-    if (n_range <= 0) return 0;
+    if (n_range < 0) n_range = 0;
     FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, i0, n_range, 0xFFFFFFFFu, nullptr, nullptr, L.n_owned_v, eu};
     if (ghost) f.ghost_out = L.xv.ghostbuf;
     else if (L.xv.n_export > 0) { f.recv_base = (uint32_t)bt.n_shared_slots; f.recv = L.xv.expbuf; }
-    const dim3 grid((unsigned)((n_range + 255) / 256)), block(256);
-    if (L.dim == 3) hipLaunchKernelGGL((k_fix<3>), grid, block, 0, s, f);
-    else hipLaunchKernelGGL((k_fix<2>), grid, block, 0, s, f);
+    const unsigned nf = (unsigned)((n_range + 255) / 256);
+    if (!ep) {
+      if (!nf) return 0;
+      if (L.dim == 3) hipLaunchKernelGGL((k_fix<3>), dim3(nf), dim3(256), 0, s, f);
+      else hipLaunchKernelGGL((k_fix<2>), dim3(nf), dim3(256), 0, s, f);
+    } else {   // the pressure rows of the same phase in the same launch
+      PullArgs p{L.pull_ptr_p, L.pull_list_p, slots_p, L.cmask_p, 0, 0, 0, nullptr, nullptr, *ep};
+      const uint32_t recv_base = (uint32_t)((L.dim == 3 ? 8 : 4) * (size_t)L.cstride);
+      const unsigned np = pull_phase(p, L.xp, L.n_nodes_p, L.n_owned_p, recv_base, pphase) ? (unsigned)((p.n_range + 255) / 256) : 0u;
+      if (nf + np == 0) return 0;
+      if (L.dim == 3) hipLaunchKernelGGL((k_fix_pull<3>), dim3(nf + np), dim3(256), 0, s, f, p, nf);
+      else hipLaunchKernelGGL((k_fix_pull<2>), dim3(nf + np), dim3(256), 0, s, f, p, nf);
+    }
     AGMG_HIP_CHECK(hipGetLastError());
     return 0;
   };
@@ -1379,18 +1392,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
   }
 #endif
   if (phase == PH_GHOST || phase == PH_INTERFACE) return fix(bt.n_shared_owned, bt.n_shared - bt.n_shared_owned, true);
-  if (!ep) return fix(0, bt.n_shared, false);
-  if (bt.n_shared <= 0) return launch_pull_p(s, L, slots_p, 1, *ep, PH_ALL);
-  {  // one launch for the velocity fix-up and the pressure pull
-    FixArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, 0, bt.n_shared, 0xFFFFFFFFu, nullptr, nullptr, L.n_owned_v, eu};
-    PullArgs p{L.pull_ptr_p, L.pull_list_p, slots_p, L.cmask_p, 0, L.n_nodes_p, 0xFFFFFFFFu, nullptr, nullptr, *ep};
-    const unsigned nf = (unsigned)((bt.n_shared + 255) / 256), np = (unsigned)((L.n_nodes_p + 255) / 256);
-    const dim3 grid(nf + np), block(256);
-    if (L.dim == 3) hipLaunchKernelGGL((k_fix_pull<3>), grid, block, 0, s, f, p, nf);
-    else hipLaunchKernelGGL((k_fix_pull<2>), grid, block, 0, s, f, p, nf);
-    AGMG_HIP_CHECK(hipGetLastError());
-  }
-  return 0;
+  return fix(0, bt.n_shared, false);
 }
 
 }  // namespace agmg
