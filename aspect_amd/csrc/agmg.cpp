@@ -351,7 +351,9 @@ struct agmg_ctx {
   bool use_sym = true, sym_now = false;
   std::vector<const double *> sym_rhs_valid;   // per level: the right-hand side whose ghost entries the pre-smoother made valid
   int n_sym_applications = 0;     // (tests)
-  bool mass_sym(const DeviceLevel &lv, const CoeffData &cd) const { return use_sym && ldist(lv) && lv.sp.active() && mass_ell(lv, cd); }
+  bool mass_sym_local(const DeviceLevel &lv, const CoeffData &cd) const { return use_sym && ldist(lv) && lv.sp.active() && mass_ell(lv, cd); }
+  // (the message pattern differs from the two-round form: every rank must take the same path, agreed at agmg_compute_diagonals)
+  bool mass_sym(const DeviceLevel &lv, const CoeffData &cd) const { return lv.sym_agreed && &cd == &lv.coeff && mass_sym_local(lv, cd); }
   int apply_mass_sym(const DeviceLevel &lv, const CoeffData &cd, const double *x, const EpiArgs &e);
   bool use_batched_setup = true;   // eigenvalue estimates of all levels in lock step (AGMG_NO_BATCHED_SETUP=1: one by one)
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
@@ -3269,8 +3271,15 @@ int agmg_compute_diagonals(agmg_ctx *c) {
       CHECK(c->exchange(m));
       CHECK(launch_pull_v(c->stream, l, c->slots_u, eA, PH_OWNED));
       CHECK(launch_pull_p(c->stream, l, c->slots_p, 1, eM, PH_OWNED));
-      // (the symmetric smoother sequences apply the update to the ghost copies too: they read the diagonal there)
-      if (l.sp.active()) CHECK(c->update_ghosts(l.xp, l.inv_diag_M));
+      // the one-round smoother sequences apply the update to the ghost copies too, so they read the diagonal there; they
+      // run only where EVERY rank can (a rank without assembled rows, e.g. at an irregular vertex of its mesh, would
+      // otherwise wait in another message pattern)
+      if (c->ldist(l)) {
+        CHECK(c->update_ghosts(l.xp, l.inv_diag_M));
+        double can = c->mass_sym_local(l, l.coeff) ? 1.0 : 0.0;
+        CHECK(c->allreduce_host(&can, 1));
+        l.sym_agreed = can == (double)c->opt.world_size;
+      }
     }
   }
   CHECK(c->sync());

@@ -173,6 +173,7 @@ struct DeviceLevel {
   bool replicated = false;           // distributed context: every rank holds this level whole (agmg_level_desc::replicated)
   Exchange xv, xp;
   SymExchange sp;                  // pressure nodes, optional
+  bool sym_agreed = false;         // every rank can run the one-round mass application on this level (agmg_compute_diagonals)
   uint32_t *gid_v = nullptr, *gid_p = nullptr;  // global node index of each local node (nullptr: identity)
   int cstride = 0;                 // padded cell count (SoA row stride)
   // SoA tables: [local index][cstride]
