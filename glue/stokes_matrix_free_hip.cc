@@ -36,6 +36,7 @@ extern "C" {
 #include "agmg.h"
 }
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <map>
@@ -496,6 +497,19 @@ namespace aspect
         d.recv_offsets_p = recv_off_p.data();
         d.global_nodes_v = global_v.data();
         d.global_nodes_p = global_p.data();
+        // one message round per mass application inside the Schur smoother (optional)
+        std::vector<int32_t> sym_rank, sym_off;
+        std::vector<uint32_t> sym_nodes;
+        if (Utilities::MPI::n_mpi_processes(this->get_mpi_communicator()) > 1)
+          {
+            build_symmetric_plan(part_p, this->get_mpi_communicator(), sym_rank, sym_off, sym_nodes);
+            d.n_sym_neighbors_p = static_cast<int32_t>(sym_rank.size());
+            d.sym_neighbor_rank_p = sym_rank.data();
+            d.sym_offsets_p = sym_off.data();
+            d.sym_nodes_p = sym_nodes.data();
+          }
+        // (d.replicated stays 0: deal.II partitions every level.  Holding the coarsest levels whole on every rank, INTEGRATION.md,
+        // needs the level's cells and DoF tables of all ranks: a serial copy of the coarse levels of the triangulation.)
         check(agmg_set_level(ctx, static_cast<int>(level), &d), "agmg_set_level");
       }
 
@@ -548,6 +562,61 @@ namespace aspect
             send_off_p.push_back(static_cast<int32_t>(send_nodes_p.size()));
             recv_off_v.push_back(recv_off_v.back() + rv[x.first]);
             recv_off_p.push_back(recv_off_p.back() + rp[x.first]);
+          }
+      }
+
+      // Symmetric exchange plan of the pressure nodes (agmg_level_desc::sym_*; optional: the one-round Schur smoother).
+      // deal.II's partitioner knows owner -> ghost only, so the owner mediates: it knows who ghosts each of its nodes
+      // (import_targets / import_indices) and tells every holder of a node who the other holders are (one
+      // some_to_some); each rank then lists, per rank it shares a node with, ascending, its local nodes in the order of
+      // the global index -- both sides build the same order without talking to each other.
+      static void build_symmetric_plan(const Utilities::MPI::Partitioner &part, const MPI_Comm comm,
+                                       std::vector<int32_t> &sym_rank, std::vector<int32_t> &sym_off, std::vector<uint32_t> &sym_nodes)
+      {
+        const unsigned int me = Utilities::MPI::this_mpi_process(comm);
+        // holders[local owned node] = ranks that ghost it
+        std::map<unsigned int, std::vector<unsigned int>> holders;
+        {
+          std::vector<unsigned int> flat;
+          for (const auto &r : part.import_indices())
+            for (unsigned int i = r.first; i < r.second; ++i) flat.push_back(i);
+          unsigned int k = 0;
+          for (const auto &t : part.import_targets())
+            for (unsigned int i = 0; i < t.second; ++i, ++k) holders[flat[k]].push_back(t.first);
+        }
+        // shared[rank] = global indices of the nodes I hold together with that rank
+        std::map<unsigned int, std::vector<types::global_dof_index>> shared, tell;
+        for (const auto &h : holders)
+          {
+            const types::global_dof_index g = part.local_to_global(h.first);
+            for (const unsigned int a : h.second)
+              {
+                shared[a].push_back(g);                       // owner <-> ghoster
+                for (const unsigned int b : h.second)
+                  if (b != a) { tell[a].push_back(g); tell[a].push_back(b); }   // ghoster <-> ghoster, by way of the owner
+              }
+          }
+        for (const auto &msg : Utilities::MPI::some_to_some(comm, tell))
+          for (std::size_t i = 0; i + 1 < msg.second.size(); i += 2)
+            shared[static_cast<unsigned int>(msg.second[i + 1])].push_back(msg.second[i]);
+        // my ghosts and their owners
+        for (unsigned int gh = 0; gh < part.n_ghost_indices(); ++gh)
+          {
+            const types::global_dof_index g = part.local_to_global(part.locally_owned_size() + gh);
+            unsigned int owner = 0, seen = 0;
+            for (const auto &t : part.ghost_targets())
+              { if (gh < seen + t.second) { owner = t.first; break; } seen += t.second; }
+            shared[owner].push_back(g);
+          }
+        sym_rank.clear(); sym_off.assign(1, 0); sym_nodes.clear();
+        for (auto &x : shared)                                // std::map: ascending ranks
+          {
+            if (x.first == me || x.second.empty()) continue;
+            std::sort(x.second.begin(), x.second.end());
+            x.second.erase(std::unique(x.second.begin(), x.second.end()), x.second.end());
+            sym_rank.push_back(static_cast<int32_t>(x.first));
+            for (const types::global_dof_index g : x.second) sym_nodes.push_back(static_cast<uint32_t>(part.global_to_local(g)));
+            sym_off.push_back(static_cast<int32_t>(sym_nodes.size()));
           }
       }
 
