@@ -125,7 +125,7 @@ def main():
         # (tests/test_host_and_abi.py: the tables equal the partition of the global mesh entry for entry)
         g = cases.convection_box(3, refinement or args.refinement)
         g.reps, g.extents = reps, [float(r) for r in reps]
-        # the coarsest levels (at most 4096 cells in the whole mesh) are held whole by every rank: no ghost exchange on
+        # the coarsest levels (at most 32768 cells in the whole mesh) are held whole by every rank: no ghost exchange on
         # them, one sum over ranks where the V-cycle steps onto them (AGMG_REPLICATED=<k> overrides, 0 = every level
         # partitioned as in the reference)
         ref_ = refinement or args.refinement
