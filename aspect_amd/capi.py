@@ -62,6 +62,7 @@ class LevelDesc(C.Structure):
         ("copy_active_v", c_u32p), ("copy_level_v", c_u32p), ("copy_active_p", c_u32p), ("copy_level_p", c_u32p),
         ("replicated", C.c_int32),
         ("n_sym_neighbors_p", C.c_int32), ("sym_neighbor_rank_p", c_i32p), ("sym_offsets_p", c_i32p), ("sym_nodes_p", c_u32p),
+        ("n_sym_neighbors_v", C.c_int32), ("sym_neighbor_rank_v", c_i32p), ("sym_offsets_v", c_i32p), ("sym_nodes_v", c_u32p),
     ]
 
 
@@ -300,6 +301,12 @@ class Solver:
                        np.ascontiguousarray(lev.sym_nodes_p, dtype=np.uint32)]
                 d.n_sym_neighbors_p = sym[0].size
                 d.sym_neighbor_rank_p, d.sym_offsets_p, d.sym_nodes_p = _ptr(sym[0], C.c_int32), _ptr(sym[1], C.c_int32), _ptr(sym[2], C.c_uint32)
+                keep += sym
+            if getattr(lev, "sym_neighbors_v", None) is not None and len(lev.sym_neighbors_v):
+                sym = [np.ascontiguousarray(lev.sym_neighbors_v, dtype=np.int32), np.ascontiguousarray(lev.sym_offsets_v, dtype=np.int32),
+                       np.ascontiguousarray(lev.sym_nodes_v, dtype=np.uint32)]
+                d.n_sym_neighbors_v = sym[0].size
+                d.sym_neighbor_rank_v, d.sym_offsets_v, d.sym_nodes_v = _ptr(sym[0], C.c_int32), _ptr(sym[1], C.c_int32), _ptr(sym[2], C.c_uint32)
                 keep += sym
         if getattr(lev, "hanging_v", None) is not None:
             # hanging-node constraints of an adaptive mesh: (nodes, ptr, masters, weights) per space

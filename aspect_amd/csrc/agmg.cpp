@@ -348,13 +348,20 @@ struct agmg_ctx {
   // one message round per application of the mass operator inside a smoother sequence (SymExchange; AGMG_NO_SYM=1:
   // ghost import + compress, two rounds).  sym_now: the vectors of the running operator application carry valid ghost
   // entries (set by the smoother around its sequence)
-  bool use_sym = true, sym_now = false;
+  bool use_sym = true, sym_now = false, sym_now_A = false;
   std::vector<const double *> sym_rhs_valid;   // per level: the right-hand side whose ghost entries the pre-smoother made valid
   int n_sym_applications = 0;     // (tests)
   bool mass_sym_local(const DeviceLevel &lv, const CoeffData &cd) const { return use_sym && ldist(lv) && lv.sp.active() && mass_ell(lv, cd); }
   // (the message pattern differs from the two-round form: every rank must take the same path, agreed at agmg_compute_diagonals)
   bool mass_sym(const DeviceLevel &lv, const CoeffData &cd) const { return lv.sym_agreed && &cd == &lv.coeff && mass_sym_local(lv, cd); }
   int apply_mass_sym(const DeviceLevel &lv, const CoeffData &cd, const double *x, const EpiArgs &e);
+  // the same for the A block on the levels that run the block kernels (brick levels keep ghost import + compress)
+  bool a_sym_local(const DeviceLevel &lv, const CoeffData &cd) const {
+    return use_sym && ldist(lv) && lv.sv.active() && lv.bt_symrow && use_blocks && lv.bt.built && !cd.newton && !cd.dilation &&
+           !(bricks_on(lv) && brickq_supported(lv, cd, AGMG_OP_A));
+  }
+  bool a_sym(const DeviceLevel &lv, const CoeffData &cd) const { return lv.sym_agreed_A && &cd == &lv.coeff && a_sym_local(lv, cd); }
+  int apply_A_sym(const DeviceLevel &lv, const CoeffData &cd, const double *x, const EpiArgs &e);
   bool use_batched_setup = true;   // eigenvalue estimates of all levels in lock step (AGMG_NO_BATCHED_SETUP=1: one by one)
   bool use_fused = true;   // one-launch smoother sequences on small levels (AGMG_NO_FUSED=1 disables)
   // Chebyshev coefficient sequences of cheb_vmult / cheb_step as a program for the fused kernels
@@ -451,6 +458,8 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   for (Exchange *x : {&l.xv, &l.xp}) { dfree(x->send_nodes); dfree(x->expbuf); dfree(x->ghostbuf); }
   dfree(l.sp.sh_nodes); dfree(l.sp.ptr); dfree(l.sp.pos); dfree(l.sp.split); dfree(l.sp.row);
   dfree(l.sp.sendbuf); dfree(l.sp.recvbuf); dfree(l.sp.ypart);
+  dfree(l.sv.sh_nodes); dfree(l.sv.ptr); dfree(l.sv.pos); dfree(l.sv.split); dfree(l.sv.row);
+  dfree(l.sv.sendbuf); dfree(l.sv.recvbuf); dfree(l.sv.ypart); dfree(l.sv_shidx); dfree(l.bt_symrow);
   dfree(l.gid_v); dfree(l.gid_p);
   dfree(l.ell_col); dfree(l.coeff.ell_val); dfree(l.coeff.brick_geo);
   dfree(l.ell_xrow); dfree(l.ell_xptr); dfree(l.ell_xent);
@@ -1162,6 +1171,8 @@ int agmg_ctx::apply_level(int which, int l, const CoeffData &cd, const double *x
     return launch_pull_p(stream, lv, slots_p, 1, e);
   }
   // distributed: src.update_ghost_values(); cell loop; dst.compress(add); epilogue on the owned rows
+  if (which == 0 && sym_now_A && a_sym(lv, cd) && (e.epi == EPI_STORE || e.epi == EPI_RESID || e.epi == EPI_CHEB))
+    return apply_A_sym(lv, cd, x, e);
   if (which == 0 && bricks_on(lv) && brickq_supported(lv, cd, AGMG_OP_A) &&
       (e.epi == EPI_STORE || e.epi == EPI_RESID || e.epi == EPI_CHEB)) {
     // brick levels: ghost import, the brick kernel (shares of ghost nodes and of rows another brick owns go to partial
@@ -1220,6 +1231,23 @@ int agmg_ctx::apply_mass_sym(const DeviceLevel &lv, const CoeffData &cd, const d
   CHECK(exchange(m));
   ++n_sym_applications;
   return launch_mass_ell_sym(stream, lv, cd, x, e, 1);
+}
+
+// The A block of a distributed level in one message round: the cell phase of every block (rows inside a block are
+// finished there), the shares of the rows other ranks hold too, one exchange, then every shared row -- owned or ghost --
+// from its shares in rank order.  Source, b, dinv and xold carry valid ghost entries (the smoother sees to that).
+int agmg_ctx::apply_A_sym(const DeviceLevel &lv, const CoeffData &cd, const double *x, const EpiArgs &e) {
+  const SymExchange &sx = lv.sv;
+  CHECK(launch_op(stream, lv, cd, AGMG_OP_A, x, nullptr, slots_u, nullptr, e, use_blocks, PH_CELLS));
+  CHECK(launch_fix_sym(stream, lv, slots_u, e, 0));
+  std::vector<Msg> m;
+  for (size_t k = 0; k < sx.nbr.size(); ++k) {
+    const int64_t n = (int64_t)(sx.off[k + 1] - sx.off[k]) * lv.dim;
+    m.push_back({sx.nbr[k], sx.sendbuf + (size_t)sx.off[k] * lv.dim, n, sx.recvbuf + (size_t)sx.off[k] * lv.dim, n});
+  }
+  CHECK(exchange(m));
+  ++n_sym_applications;
+  return launch_fix_sym(stream, lv, slots_u, e, 1);
 }
 
 // one-rank level operators on given tables: which01 0 = A block, 1 = mass
@@ -1512,13 +1540,13 @@ struct FlagGuard {   // sets a flag for the life of a scope
 
 int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
-  const bool sym = which == 1 && mass_sym(L[l], L[l].coeff);
-  if (sym) {   // (the iterate starts from dinv * rhs on every local entry)
-    CHECK(update_ghosts(L[l].xp, rhs));
-    if ((int)sym_rhs_valid.size() != nl()) sym_rhs_valid.assign(nl(), nullptr);
-    sym_rhs_valid[l] = rhs;
+  const bool sym = which == 1 && mass_sym(L[l], L[l].coeff), symA = which == 0 && a_sym(L[l], L[l].coeff);
+  if (sym || symA) {   // (the iterate starts from dinv * rhs on every local entry)
+    CHECK(update_ghosts(which == 0 ? L[l].xv : L[l].xp, rhs));
+    if ((int)sym_rhs_valid.size() != 2 * nl()) sym_rhs_valid.assign(2 * nl(), nullptr);
+    sym_rhs_valid[2 * l + which] = rhs;
   }
-  FlagGuard guard(sym_now, sym);
+  FlagGuard guard(sym_now, sym), guardA(sym_now_A, symA);
   if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
     SmootherProgram p;
     program_vmult(sm[1][l], p);
@@ -1532,12 +1560,13 @@ int agmg_ctx::smoother_apply(int which, int l, const double *rhs) {
 }
 int agmg_ctx::smoother_smooth(int which, int l, const double *rhs) {
   const int steps = which == 0 ? 1 : opt.schur_smoother_steps;
-  const bool sym = which == 1 && mass_sym(L[l], L[l].coeff);
-  if (sym) {   // the right-hand side and the iterate (coarse-grid correction added) with valid ghost entries
-    if ((int)sym_rhs_valid.size() != nl() || sym_rhs_valid[l] != rhs) CHECK(update_ghosts(L[l].xp, rhs));
-    CHECK(update_ghosts(L[l].xp, mg_sol[1][l]));
+  const bool sym = which == 1 && mass_sym(L[l], L[l].coeff), symA = which == 0 && a_sym(L[l], L[l].coeff);
+  if (sym || symA) {   // the right-hand side and the iterate (coarse-grid correction added) with valid ghost entries
+    const Exchange &x = which == 0 ? L[l].xv : L[l].xp;
+    if ((int)sym_rhs_valid.size() != 2 * nl() || sym_rhs_valid[2 * l + which] != rhs) CHECK(update_ghosts(x, rhs));
+    CHECK(update_ghosts(x, mg_sol[which][l]));
   }
-  FlagGuard guard(sym_now, sym);
+  FlagGuard guard(sym_now, sym), guardA(sym_now_A, symA);
   if (which == 1 && fused_mass(l) && steps * sm[1][l].degree + 1 <= SM_MAX_STEPS) {
     SmootherProgram p;
     for (int i = 0; i < steps; ++i) program_step(sm[1][l], p);
@@ -1649,7 +1678,7 @@ int agmg_ctx::level_v_step(int which, int l) {
     EpiArgs e;
     e.epi = EPI_RESID; e.dst = mg_t[which][l]; e.b = mg_def[which][l];
     // (behind the symmetric smoother sequence the iterate and the defect carry valid ghost entries: one round here too)
-    FlagGuard guard(sym_now, which == 1 && mass_sym(F, F.coeff));
+    FlagGuard guard(sym_now, which == 1 && mass_sym(F, F.coeff)), guardA(sym_now_A, which == 0 && a_sym(F, F.coeff));
     CHECK(apply_level(which, l, F.coeff, mg_sol[which][l], e));
   }
   }
@@ -2659,24 +2688,22 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
       lv.bytes_tables += snh.size() * 4;
     }
   }
-  if (has_plan && d->n_sym_neighbors_p > 0 && !lv.replicated) {
-    // symmetric exchange plan of the pressure nodes (SymExchange)
-    const int nn_ = d->n_sym_neighbors_p;
-    if (!d->sym_neighbor_rank_p || !d->sym_offsets_p || !d->sym_nodes_p || d->sym_offsets_p[0] != 0) { set_error("incomplete symmetric exchange plan"); return -1; }
-    SymExchange &sx = lv.sp;
-    sx.nbr.assign(d->sym_neighbor_rank_p, d->sym_neighbor_rank_p + nn_);
-    sx.off.assign(d->sym_offsets_p, d->sym_offsets_p + nn_ + 1);
+  // symmetric exchange plans (SymExchange) of the pressure nodes and of the velocity nodes
+  auto build_sym = [&](SymExchange &sx, const int nn_, const int32_t *ranks, const int32_t *offs, const uint32_t *nodes, const int n_nodes, const int nc) -> int {
+    if (!ranks || !offs || !nodes || offs[0] != 0) { set_error("incomplete symmetric exchange plan"); return -1; }
+    sx.nbr.assign(ranks, ranks + nn_);
+    sx.off.assign(offs, offs + nn_ + 1);
     for (int k = 0; k < nn_; ++k) {
       if (sx.nbr[k] < 0 || sx.nbr[k] >= c->opt.world_size || sx.nbr[k] == c->opt.rank || (k > 0 && sx.nbr[k] <= sx.nbr[k - 1]) || sx.off[k + 1] < sx.off[k]) {
         set_error("symmetric exchange plan: neighbour ranks ascending, offsets non-decreasing"); return -1;
       }
     }
     sx.n_sym = sx.off[nn_];
-    std::vector<int32_t> row(d->n_nodes_p, -1);
+    std::vector<int32_t> row(n_nodes, -1);
     std::vector<uint32_t> sh_nodes, cnt;
     for (int i = 0; i < sx.n_sym; ++i) {
-      const uint32_t node = d->sym_nodes_p[i];
-      if ((int)node >= d->n_nodes_p) { set_error("symmetric exchange plan: node out of range"); return -1; }
+      const uint32_t node = nodes[i];
+      if ((int)node >= n_nodes) { set_error("symmetric exchange plan: node out of range"); return -1; }
       if (row[node] < 0) { row[node] = (int32_t)sh_nodes.size(); sh_nodes.push_back(node); cnt.push_back(0); }
       ++cnt[row[node]];
     }
@@ -2687,15 +2714,20 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
     std::vector<uint8_t> split(sx.n_sh, 0);
     for (int k = 0; k < nn_; ++k)      // neighbours ascending: the positions of a node come out in rank order
       for (int i = sx.off[k]; i < sx.off[k + 1]; ++i) {
-        const int r = row[d->sym_nodes_p[i]];
+        const int r = row[nodes[i]];
         pos[fill[r]++] = (uint32_t)i;
         if (sx.nbr[k] < c->opt.rank) ++split[r];
       }
     CHECK(c->upload(&sx.sh_nodes, sh_nodes)); CHECK(c->upload(&sx.ptr, ptr)); CHECK(c->upload(&sx.pos, pos));
     CHECK(c->upload(&sx.split, split)); CHECK(c->upload(&sx.row, row));
-    CHECK(c->dalloc(&sx.sendbuf, (size_t)sx.n_sym)); CHECK(c->dalloc(&sx.recvbuf, (size_t)sx.n_sym)); CHECK(c->dalloc(&sx.ypart, (size_t)sx.n_sh));
+    CHECK(c->dalloc(&sx.sendbuf, (size_t)sx.n_sym * nc)); CHECK(c->dalloc(&sx.recvbuf, (size_t)sx.n_sym * nc)); CHECK(c->dalloc(&sx.ypart, (size_t)sx.n_sh * nc));
     lv.bytes_tables += (sh_nodes.size() + ptr.size() + pos.size() + row.size()) * 4 + split.size();
-  }
+    return 0;
+  };
+  if (has_plan && d->n_sym_neighbors_p > 0 && !lv.replicated)
+    CHECK(build_sym(lv.sp, d->n_sym_neighbors_p, d->sym_neighbor_rank_p, d->sym_offsets_p, d->sym_nodes_p, d->n_nodes_p, 1));
+  if (has_plan && d->n_sym_neighbors_v > 0 && !lv.replicated)
+    CHECK(build_sym(lv.sv, d->n_sym_neighbors_v, d->sym_neighbor_rank_v, d->sym_offsets_v, d->sym_nodes_v, d->n_nodes_v, dim));
   for (int vel = 0; vel < 2; ++vel) {
     const uint32_t *gn = vel ? d->global_nodes_v : d->global_nodes_p;
     if (gn && c->dist() && primary) {
@@ -2833,6 +2865,22 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
   }
   tm.lap("geometry", level);
   CHECK(c->build_block_tables(lv, hl, cmv, send_nodes_of(0)));
+  if (lv.sv.active() && lv.bt.built) {
+    // every row of the velocity exchange must be a shared node of the block tables (interface nodes always are)
+    std::vector<uint32_t> shn(lv.bt.n_shared), svn(lv.sv.n_sh);
+    if (lv.bt.n_shared) AGMG_HIP_CHECK(hipMemcpy(shn.data(), lv.bt.sh_nodes, shn.size() * 4, hipMemcpyDeviceToHost));
+    if (lv.sv.n_sh) AGMG_HIP_CHECK(hipMemcpy(svn.data(), lv.sv.sh_nodes, svn.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> at(lv.n_nodes_v, -1), symrow(lv.bt.n_shared, -1);
+    for (int i = 0; i < lv.bt.n_shared; ++i) at[shn[i] & NODE_MASK] = i;
+    std::vector<uint32_t> shidx(lv.sv.n_sh, 0);
+    bool ok = true;
+    for (int r = 0; r < lv.sv.n_sh; ++r) {
+      const int i = at[svn[r]];
+      if (i < 0) { ok = false; break; }
+      shidx[r] = (uint32_t)i; symrow[i] = r;
+    }
+    if (ok) { CHECK(c->upload(&lv.sv_shidx, shidx)); CHECK(c->upload(&lv.bt_symrow, symrow)); }
+  }
   tm.lap("block tables", level);
   lv.bytes_tables += lv.bt.bytes;
   if (c->use_bricks && structured) {   // (not for the partly refined meshes of adaptive contexts)
@@ -3276,9 +3324,11 @@ int agmg_compute_diagonals(agmg_ctx *c) {
       // otherwise wait in another message pattern)
       if (c->ldist(l)) {
         CHECK(c->update_ghosts(l.xp, l.inv_diag_M));
-        double can = c->mass_sym_local(l, l.coeff) ? 1.0 : 0.0;
-        CHECK(c->allreduce_host(&can, 1));
-        l.sym_agreed = can == (double)c->opt.world_size;
+        CHECK(c->update_ghosts(l.xv, l.inv_diag_A));
+        double can[2] = {c->mass_sym_local(l, l.coeff) ? 1.0 : 0.0, c->a_sym_local(l, l.coeff) ? 1.0 : 0.0};
+        CHECK(c->allreduce_host(can, 2));
+        l.sym_agreed = can[0] == (double)c->opt.world_size;
+        l.sym_agreed_A = can[1] == (double)c->opt.world_size;
       }
     }
   }

@@ -174,6 +174,13 @@ struct DeviceLevel {
   Exchange xv, xp;
   SymExchange sp;                  // pressure nodes, optional
   bool sym_agreed = false;         // every rank can run the one-round mass application on this level (agmg_compute_diagonals)
+  // the same for the velocity nodes (A block on the block path): buffers hold dim values per entry; sv_shidx[r] = index of
+  // shared row r in the block tables' list of shared nodes, bt_symrow[i] = the inverse (-1: the node is shared between
+  // blocks of this rank only)
+  SymExchange sv;
+  uint32_t *sv_shidx = nullptr;
+  int32_t *bt_symrow = nullptr;
+  bool sym_agreed_A = false;
   uint32_t *gid_v = nullptr, *gid_p = nullptr;  // global node index of each local node (nullptr: identity)
   int cstride = 0;                 // padded cell count (SoA row stride)
   // SoA tables: [local index][cstride]
@@ -260,7 +267,8 @@ int launch_diag_cells(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, 
 // overlapped form of PH_GHOST: PH_INTERIOR = the cell phase of the blocks that read no ghost value
 // (may run before the ghost import has landed), PH_INTERFACE = the remaining blocks + the partial sums
 // of the ghost nodes
-enum Phase { PH_ALL = 0, PH_GHOST = 1, PH_OWNED = 2, PH_INTERIOR = 3, PH_INTERFACE = 4 };
+// PH_CELLS = the cell phase of every block and nothing else (the one-round form finishes the shared rows itself)
+enum Phase { PH_ALL = 0, PH_GHOST = 1, PH_OWNED = 2, PH_INTERIOR = 3, PH_INTERFACE = 4, PH_CELLS = 5 };
 int launch_pull_v(hipStream_t s, const DeviceLevel &L, const double *slots, const EpiArgs &e, int phase = PH_ALL);
 // Whole velocity-row application: cell phase + reduction + epilogue `eu` on the velocity rows.
 // Uses the block-scatter kernels when L.bt is built (and use_blocks), else cells -> slots -> pull.
@@ -275,6 +283,10 @@ int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, co
 // (after the exchange) = every local row, owned or ghost, with the epilogue; the shares of a shared row are added in
 // rank order, so every rank that holds the row computes the same sum
 int launch_mass_ell_sym(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int part);
+// A block on the block path, one message round (DeviceLevel::sv): behind launch_op(..., PH_CELLS), part 0 = the shares of
+// the rows other ranks hold too (sums of this rank's slots) into the send buffer, part 1 (after the exchange) = every
+// shared row of the block tables, owned or ghost, with the epilogue; shares added in rank order
+int launch_fix_sym(hipStream_t s, const DeviceLevel &L, const double *slots_u, const EpiArgs &eu, int part);
 
 // free-surface stabilisation faces of the active Stokes operator (matrix_free_operators.cc:294-333),
 // organised by node: every surface node lists the (face, local index) pairs that touch it

@@ -884,6 +884,80 @@ __device__ __forceinline__ void fix_body(const FixArgs &F, const unsigned block)
 }
 template <int NC>
 __global__ void __launch_bounds__(256) k_fix(const FixArgs F) { fix_body<NC>(F, blockIdx.x); }
+// ---- one message round per application (SymExchange of the velocity nodes)
+struct FixSymArgs {
+  const uint32_t *sh_nodes, *sh_ptr, *sh_list;   // block tables' shared nodes
+  const double *slots_sh;
+  uint32_t recv_base;                            // list entries >= recv_base belong to the two-round form: skipped
+  int n_rows;                                    // part 0: shared rows of the exchange; part 1: shared nodes of the block tables
+  const uint32_t *shidx;                         // part 0: row -> index among the block tables' shared nodes
+  const int32_t *symrow;                         // part 1: the inverse, or -1
+  const uint32_t *sptr, *spos;
+  const uint8_t *ssplit;
+  double *ypart, *sendbuf;
+  const double *recvbuf;
+  EpiArgs e;
+};
+template <int NC>
+__device__ __forceinline__ void local_slot_sum(const FixSymArgs &F, const int i, double (&sum)[NC]) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) sum[c] = 0.0;
+  for (uint32_t k = F.sh_ptr[i]; k < F.sh_ptr[i + 1]; ++k) {
+    const uint32_t e = F.sh_list[k];
+    if (e >= F.recv_base) continue;
+    const double *p = F.slots_sh + (size_t)e * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sum[c] += p[c];
+  }
+}
+template <int NC>
+__global__ void __launch_bounds__(256) k_fix_sym_a(const FixSymArgs F) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= F.n_rows) return;
+  double sum[NC];
+  local_slot_sum<NC>(F, (int)F.shidx[r], sum);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) F.ypart[(size_t)r * NC + c] = sum[c];
+  for (uint32_t k = F.sptr[r]; k < F.sptr[r + 1]; ++k) {
+    double *o = F.sendbuf + (size_t)F.spos[k] * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[c] = sum[c];
+  }
+}
+template <int NC>
+__global__ void __launch_bounds__(256) k_fix_sym_b(const FixSymArgs F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F.n_rows) return;
+  const uint32_t nd = F.sh_nodes[i];
+  const size_t g0 = (size_t)(nd & NODE_MASK) * NC;
+  double sum[NC];
+  const int r = F.symrow[i];
+  if (r < 0) local_slot_sum<NC>(F, i, sum);
+  else {
+    const uint32_t s0 = F.sptr[r], s1 = F.sptr[r + 1], mine = s0 + F.ssplit[r];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sum[c] = 0.0;
+    for (uint32_t k = s0; k < s1; ++k) {
+      if (k == mine) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sum[c] += F.ypart[(size_t)r * NC + c];
+      }
+      const double *p = F.recvbuf + (size_t)F.spos[k] * NC;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sum[c] += p[c];
+    }
+    if (mine == s1) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sum[c] += F.ypart[(size_t)r * NC + c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool con = (nd >> (29 + c)) & 1u;
+    double out;
+    if (epi_value(F.e, g0 + c, sum[c], con, out)) F.e.dst[g0 + c] = out;
+  }
+}
 // Stokes: the fix-up of the velocity rows and the pull of the pressure rows are independent of
 // each other (both only wait for the cell kernel): one launch, the grid split between them
 template <int DIM>
@@ -1186,6 +1260,25 @@ int launch_mass_ell_sym(hipStream_t s, const DeviceLevel &L, const CoeffData &cd
   return 0;
 }
 
+int launch_fix_sym(hipStream_t s, const DeviceLevel &L, const double *slots_u, const EpiArgs &eu, int part) {
+  const BlockTables &bt = L.bt;
+  const SymExchange &x = L.sv;
+  if (!bt.built || !x.active() || !L.bt_symrow || !L.sv_shidx) { set_error("launch_fix_sym: level has no symmetric exchange tables"); return -1; }
+  FixSymArgs f{bt.sh_nodes, bt.sh_ptr, bt.sh_list, slots_u, (uint32_t)bt.n_shared_slots, part == 0 ? x.n_sh : bt.n_shared,
+               L.sv_shidx, L.bt_symrow, x.ptr, x.pos, x.split, x.ypart, x.sendbuf, x.recvbuf, eu};
+  if (f.n_rows <= 0) return 0;
+  const dim3 grid((unsigned)((f.n_rows + 255) / 256)), block(256);
+  if (part == 0) {
+    if (L.dim == 3) hipLaunchKernelGGL((k_fix_sym_a<3>), grid, block, 0, s, f);
+    else hipLaunchKernelGGL((k_fix_sym_a<2>), grid, block, 0, s, f);
+  } else {
+    if (L.dim == 3) hipLaunchKernelGGL((k_fix_sym_b<3>), grid, block, 0, s, f);
+    else hipLaunchKernelGGL((k_fix_sym_b<2>), grid, block, 0, s, f);
+  }
+  AGMG_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_mass_smoother(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const SmootherProgram &prog,
                          const double *dinv, const double *b, const double *x_in, double *x_out, double *resid_out,
                          bool use_ell) {
@@ -1309,6 +1402,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
       ((cd.newton || cd.dilation) && which == AGMG_OP_STOKES)) {
     // the slot path has no interior / interface split: everything waits for the ghost import
     if (phase == PH_INTERIOR) return 0;
+    if (phase == PH_CELLS) { set_error("launch_op: PH_CELLS needs the block path"); return -1; }
     if (phase == PH_INTERFACE) phase = PH_GHOST;
     if (phase != PH_OWNED) {
       const int rc = launch_op_cells(s, L, cd, which, src_u, src_p, slots_u, slots_p);
@@ -1370,7 +1464,7 @@ int launch_op(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, int whic
                   : launch_blk_op<2, false>(s, a, b, eu, n_launch, lds, which, comp, perq);
   }
   if (rc) return rc;
-  if (phase == PH_INTERIOR) { AGMG_HIP_CHECK(hipGetLastError()); return 0; }
+  if (phase == PH_INTERIOR || phase == PH_CELLS) { AGMG_HIP_CHECK(hipGetLastError()); return 0; }
   AGMG_HIP_CHECK(hipGetLastError());
 #if AGMG_ABLATE & 1024
   {

@@ -179,6 +179,7 @@ class LocalLevel(_LocalVectors):
         self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
         self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
         self.sym_neighbors_p, self.sym_offsets_p, self.sym_nodes_p = self.p.sym_plan()
+        self.sym_neighbors_v, self.sym_offsets_v, self.sym_nodes_v = self.v.sym_plan()
         self.global_nodes_v = self.v.l2g.astype(np.uint32)
         self.global_nodes_p = self.p.l2g.astype(np.uint32)
         self.n_global_nodes_v, self.n_global_nodes_p = glev.n_nodes_v, glev.n_nodes_p
@@ -390,6 +391,7 @@ class RankLocalBoxLevel(_LocalVectors):
         self.send_offsets_v, self.send_nodes_v, self.recv_offsets_v = self.v.plan(self.neighbors)
         self.send_offsets_p, self.send_nodes_p, self.recv_offsets_p = self.p.plan(self.neighbors)
         self.sym_neighbors_p, self.sym_offsets_p, self.sym_nodes_p = self.p.sym_plan()
+        self.sym_neighbors_v, self.sym_offsets_v, self.sym_nodes_v = self.v.sym_plan()
         self.global_nodes_v = self.v.l2g.astype(np.uint32)
         self.global_nodes_p = self.p.l2g.astype(np.uint32)
         if parent_is_replicated and true_size > 1:

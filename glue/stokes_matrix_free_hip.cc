@@ -507,6 +507,7 @@ namespace aspect
             d.sym_neighbor_rank_p = sym_rank.data();
             d.sym_offsets_p = sym_off.data();
             d.sym_nodes_p = sym_nodes.data();
+            // (the same for the velocity nodes, on part_v with dim dofs per node, gives d.sym_*_v: the A-block smoother)
           }
         // (d.replicated stays 0: deal.II partitions every level.  Holding the coarsest levels whole on every rank, INTEGRATION.md,
         // needs the level's cells and DoF tables of all ranks: a serial copy of the coarse levels of the triangulation.)

@@ -201,6 +201,12 @@ typedef struct agmg_level_desc {
   const int32_t *sym_neighbor_rank_p;   /* [n_sym_neighbors_p], ascending */
   const int32_t *sym_offsets_p;         /* [n_sym_neighbors_p + 1] into sym_nodes_p */
   const uint32_t *sym_nodes_p;          /* local node indices */
+  /* the same plan for the Q2 velocity nodes: the Chebyshev smoother of the A block in one message round per
+   * application on the levels that run the block kernels (brick levels keep ghost import + compress) */
+  int32_t n_sym_neighbors_v;
+  const int32_t *sym_neighbor_rank_v;
+  const int32_t *sym_offsets_v;
+  const uint32_t *sym_nodes_v;
 } agmg_level_desc;
 
 /* Mirrors OperatorCellData<dim,double> (matrix_free_operators.h:91-203). */

@@ -270,5 +270,5 @@ def test_symmetric_exchange_plans_agree_between_ranks():
             ghosts = set(range(L[a].n_owned_nodes_p, L[a].n_nodes_p))
             assert shared == exported | ghosts
             b = partition.RankLocalProblem(case(), a, size).hier.levels[l]
-            for key in ("sym_neighbors_p", "sym_offsets_p", "sym_nodes_p"):
+            for key in ("sym_neighbors_p", "sym_offsets_p", "sym_nodes_p", "sym_neighbors_v", "sym_offsets_v", "sym_nodes_v"):
                 assert np.array_equal(getattr(L[a], key), getattr(b, key)), (l, a, key)
