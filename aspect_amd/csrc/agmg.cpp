@@ -349,6 +349,7 @@ struct agmg_ctx {
   // ghost import + compress, two rounds).  sym_now: the vectors of the running operator application carry valid ghost
   // entries (set by the smoother around its sequence)
   bool use_sym = true, sym_now = false, sym_now_A = false;
+  bool fine_ghosts_valid = false;   // the vector about to be restricted came out of a one-round application: no import needed
   std::vector<const double *> sym_rhs_valid;   // per level: the right-hand side whose ghost entries the pre-smoother made valid
   int n_sym_applications = 0;     // (tests)
   bool mass_sym_local(const DeviceLevel &lv, const CoeffData &cd) const { return use_sym && ldist(lv) && lv.sp.active() && mass_ell(lv, cd); }
@@ -1343,7 +1344,7 @@ int agmg_ctx::restrict_to(int which, int l, const double *src_fine, const EpiArg
   const DeviceLevel &F = L[l], &C = L[l - 1];
   const bool vel = which == 0;
   double *slots = vel ? slots_u : slots_p;
-  if (dist()) CHECK(update_ghosts(vel ? F.xv : F.xp, src_fine));
+  if (dist() && !fine_ghosts_valid) CHECK(update_ghosts(vel ? F.xv : F.xp, src_fine));
   CHECK(launch_restrict_cells(stream, F, C, vel, src_fine, slots));
   const bool mixed = dist() && C.replicated && !F.replicated;
   if ((ad.on || mixed) && l < (int)ad.rpull_ptr[vel ? 0 : 1].size() && ad.rpull_ptr[vel ? 0 : 1][l]) {
@@ -1685,6 +1686,8 @@ int agmg_ctx::level_v_step(int which, int l) {
   {  // defect[l-1] = R t   (coarse Dirichlet rows dropped); adaptive contexts: += (copy_to_mg filled the coarser defect)
     EpiArgs e;
     e.epi = ad.on ? EPI_ADD : EPI_STORE; e.dst = mg_def[which][l - 1]; e.x = nullptr;
+    // (a residual out of a one-round application carries its ghost entries already)
+    FlagGuard guard(fine_ghosts_valid, which == 1 ? mass_sym(F, F.coeff) : a_sym(F, F.coeff));
     CHECK(restrict_to(which, l, mg_t[which][l], e));
   }
   CHECK(level_v_step(which, l - 1));
