@@ -110,7 +110,7 @@ def main():
         return prob, solver, fin, src_h, fin.n_dofs_v, fin.n_dofs_p
 
     transport_name = ""
-    comm_counts = {}
+    comm_counts, comm_counts_large = {}, {}
     replicated_levels = {}
 
     def distributed_setup(refinement=None):
@@ -151,14 +151,15 @@ def main():
         tr0 = Transport(ranks)
         solver = capi.Solver(lib, loc, transport=tr0, device=local_rank)
         ref = one_vmult(solver)
-        if refinement is None:
+        if True:   # (both sizes: one more solve on the counting transport)
             _, _, _ = solver.solve(allow_failure=True)
             e0, a0 = tr0.n_exchange, tr0.n_allreduce
             _, rep_c, _ = solver.solve(allow_failure=True)
             its = max(1, rep_c.n_cheap_iterations + rep_c.n_expensive_iterations)
-            comm_counts.update({"gmres_iterations": its, "ghost_exchanges_per_iteration": (tr0.n_exchange - e0) / its,
-                                "all_reduces_per_iteration": (tr0.n_allreduce - a0) / its,
-                                "replicated_coarse_levels": n_rep, "levels": ref_ + 1})
+            (comm_counts if refinement is None else comm_counts_large).update(
+                {"gmres_iterations": its, "ghost_exchanges_per_iteration": (tr0.n_exchange - e0) / its,
+                 "all_reduces_per_iteration": (tr0.n_allreduce - a0) / its,
+                 "replicated_coarse_levels": n_rep, "levels": ref_ + 1})
         transport_name = "torch.distributed callbacks"
         want = os.environ.get("AGMG_TRANSPORT", "rccl" if backend == "nccl" else "torch")
         if want == "rccl":
@@ -318,7 +319,7 @@ def main():
                                        f"{int(nu2)}+{int(np2)} DoFs per GPU)",
                            "stokes_vmult_us": 1e6 * dt2, "gdofs": world * (nu2 + np2) / dt2 / 1e9,
                            "solve_seconds": solve2, "gmres_iterations": f"{rep_l.n_cheap_iterations}+{rep_l.n_expensive_iterations}",
-                           "solve_status": rc_l,
+                           "solve_status": rc_l, "messages_per_krylov_iteration": dict(comm_counts_large) or None,
                            "one_gpu_same_cube": {"stokes_vmult_us": 1e6 * t1, "gdofs": (f1.n_dofs_v + f1.n_dofs_p) / t1 / 1e9,
                                                  "solve_seconds": solve1,
                                                  "gmres_iterations": f"{rep_1.n_cheap_iterations}+{rep_1.n_expensive_iterations}"}}
