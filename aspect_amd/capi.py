@@ -159,6 +159,8 @@ class Library:
         self.vmult_dense = fn("vmult_dense", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         # (checker library only: the CPU baseline leg of bench.py, SIMD across cells; returns the lanes used)
         self.vmult_simd = fn("vmult_simd", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp]) if "vmult_simd" in optional or prefix != "agmg_" else None
+        self.bench_vmult_simd = (fn("bench_vmult_simd", C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp])
+                                 if prefix != "agmg_" else None)
         self.get_inverse_diagonal = fn("get_inverse_diagonal", C.c_int, [vp, C.c_int, C.c_int, c_dp])
         self.prolongate_add = fn("prolongate_add", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
         self.restrict_add = fn("restrict_add", C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp])
@@ -417,6 +419,16 @@ class Solver:
         if lanes < 0:
             raise RuntimeError("vmult_simd does not cover this level")
         return dst, lanes
+
+    def bench_vmult_simd(self, which, src, n_repeat, level=ACTIVE):
+        """Checker library only: seconds per application of vmult_simd, timed inside the library on buffers allocated
+        once (the reference's harness times the vmult alone, local_smoothing.cc:1236-1264); returns (seconds, lanes)."""
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        sec = C.c_double(0.0)
+        lanes = self.lib.bench_vmult_simd(self.ctx, which, level, int(n_repeat), _ptr(src, C.c_double), C.byref(sec))
+        if lanes < 0:
+            raise RuntimeError("vmult_simd does not cover this level")
+        return sec.value, lanes
 
     def rhs_correction(self, u0, rhs):
         """correct_stokes_rhs(): rhs - M u0 with u0 read without the constraints."""

@@ -30,6 +30,7 @@
 #include "../include/agmg.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1867,34 +1868,55 @@ int oracle_vmult_simd(oracle_ctx *o, int which, int level, double *dst, const do
   const int nu = L.ndv();
   const double *su = src, *sp = which == AGMG_OP_A ? nullptr : src + nu;
   double *du = dst, *dp = which == AGMG_OP_A ? nullptr : dst + nu;
-  std::fill(du, du + nu, 0.0);
-  if (dp) std::fill(dp, dp + L.ndp(), 0.0);
   const auto &colours = cell_colours(L);
   const int nthreads = oracle_threads();
-  for (const auto &col : colours) {
-    const int n = (int)col.size();
-    const int chunk = std::max(lanes, ((n + 8 * nthreads - 1) / (8 * nthreads) + lanes - 1) / lanes * lanes);
-    const int n_chunks = (n + chunk - 1) / chunk;
-#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
-    for (int ch = 0; ch < n_chunks; ++ch) {
-      const int first = ch * chunk, cnt = std::min(chunk, n - first);
-      kernel(mode, cd.is_compressible ? 1 : 0, cnt, col.data() + first, L.cnv.data(), L.cnp.data(), L.cmv.data(), L.cmp.data(),
-             L.cell_h.data(), cd.eta.data(), cd.nqv, cd.lambda, su, sp, du, dp);
+  const int ndp = dp ? L.ndp() : 0;
+  // one parallel region per application: zeroing, the colours one after the other (a barrier between two colours;
+  // every thread takes the same contiguous run of a colour's batches in every application, so its cells stay in its
+  // caches), the identity rows
+#pragma omp parallel num_threads(nthreads)
+  {
+#pragma omp for schedule(static)
+    for (int i = 0; i < nu; ++i) du[i] = 0.0;
+#pragma omp for schedule(static)
+    for (int i = 0; i < ndp; ++i) dp[i] = 0.0;
+    for (const auto &col : colours) {
+      const int n = (int)col.size();
+      const int chunk = 8 * lanes, n_batches = (n + chunk - 1) / chunk;
+#pragma omp for schedule(static)
+      for (int b = 0; b < n_batches; ++b) {
+        const int first = b * chunk, cnt = std::min(chunk, n - first);
+        kernel(mode, cd.is_compressible ? 1 : 0, cnt, col.data() + first, L.cnv.data(), L.cnp.data(), L.cmv.data(), L.cmp.data(),
+               L.cell_h.data(), cd.eta.data(), cd.nqv, cd.lambda, su, sp, du, dp);
+      }
+    }
+    // MatrixFreeOperators::Base::vmult: identity rows (B^T: of the velocity block, reading src_u)
+#pragma omp for schedule(static)
+    for (int n = 0; n < L.n_nodes_v; ++n)
+      if (L.cmv[n])
+        for (int c = 0; c < 3; ++c)
+          if (L.constrained_v(n, c)) du[size_t(n) * 3 + c] += su[size_t(n) * 3 + c];
+    if (dp && sp) {
+#pragma omp for schedule(static)
+      for (int n = 0; n < L.n_nodes_p; ++n)
+        if (L.constrained_p(n)) dp[n] += sp[n];
     }
   }
-  if (which != AGMG_OP_BT)
-    for (int n = 0; n < L.n_nodes_v; ++n)
-      if (L.cmv[n])
-        for (int c = 0; c < 3; ++c)
-          if (L.constrained_v(n, c)) du[size_t(n) * 3 + c] += su[size_t(n) * 3 + c];
-  if (which == AGMG_OP_BT)   // MatrixFreeOperators::Base::vmult on both blocks: identity rows of the velocity block read src_u
-    for (int n = 0; n < L.n_nodes_v; ++n)
-      if (L.cmv[n])
-        for (int c = 0; c < 3; ++c)
-          if (L.constrained_v(n, c)) du[size_t(n) * 3 + c] += su[size_t(n) * 3 + c];
-  if (dp && sp)
-    for (int n = 0; n < L.n_nodes_p; ++n)
-      if (L.constrained_p(n)) dp[n] += sp[n];
+  return lanes;
+}
+
+// The reference's harness protocol inside the library (local_smoothing.cc:1236-1264: warm-up, then the mean over
+// n_repeat applications), on buffers allocated once: seconds per application.  Returns the SIMD lanes, or -1.
+int oracle_bench_vmult_simd(oracle_ctx *o, int which, int level, int n_repeat, const double *src, double *seconds) {
+  Ctx &C = o->c;
+  const Level &L = level == AGMG_ACTIVE ? C.act() : C.levels[level];
+  const size_t n = (size_t)L.ndv() + (which == AGMG_OP_A ? 0 : (size_t)L.ndp());
+  std::vector<double> dst(n);
+  int lanes = oracle_vmult_simd(o, which, level, dst.data(), src);
+  if (lanes < 0 || n_repeat < 1) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_repeat; ++i) lanes = oracle_vmult_simd(o, which, level, dst.data(), src);
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n_repeat;
   return lanes;
 }
 
