@@ -399,7 +399,7 @@ int vec_hang_restore(hipStream_t s, double *y, const HangTables &t, int nc);
 // dst[dst_nodes[k]*nc + c] = src[src_nodes[k]*nc + c]
 int vec_copy_nodes(hipStream_t s, double *dst, const uint32_t *dst_nodes, const double *src, const uint32_t *src_nodes, int n_nodes, int nc);
 constexpr int DOT_BLOCKS = 256;
-constexpr int DOT_MAX_VECS = 8;
+constexpr int DOT_MAX_VECS = 16;   // (8 until round 3: a sweep over the Krylov basis re-reads the vector it is taken against once per chunk)
 // out[k] = <x, ys[k]> for k < nvec <= DOT_MAX_VECS; result on device in `out`
 // (workspace `partials` holds DOT_BLOCKS*DOT_MAX_VECS doubles)
 struct VecPtrs { const double *p[DOT_MAX_VECS]; };

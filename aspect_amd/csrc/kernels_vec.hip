@@ -277,16 +277,13 @@ int vec_multi_dot(hipStream_t s, const double *x, const VecPtrs &ys, int nvec, s
   if (g > DOT_BLOCKS) g = DOT_BLOCKS;
   if (g < 1) g = 1;
   const dim3 grid((unsigned)g), block(VB);
+#define AGMG_DOT_CASE(N) case N: hipLaunchKernelGGL((k_multi_dot<N>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break
   switch (nvec) {
-    case 1: hipLaunchKernelGGL((k_multi_dot<1>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    case 2: hipLaunchKernelGGL((k_multi_dot<2>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    case 3: hipLaunchKernelGGL((k_multi_dot<3>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    case 4: hipLaunchKernelGGL((k_multi_dot<4>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    case 5: hipLaunchKernelGGL((k_multi_dot<5>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    case 6: hipLaunchKernelGGL((k_multi_dot<6>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    case 7: hipLaunchKernelGGL((k_multi_dot<7>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
-    default: hipLaunchKernelGGL((k_multi_dot<8>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
+    AGMG_DOT_CASE(1); AGMG_DOT_CASE(2); AGMG_DOT_CASE(3); AGMG_DOT_CASE(4); AGMG_DOT_CASE(5); AGMG_DOT_CASE(6); AGMG_DOT_CASE(7); AGMG_DOT_CASE(8);
+    AGMG_DOT_CASE(9); AGMG_DOT_CASE(10); AGMG_DOT_CASE(11); AGMG_DOT_CASE(12); AGMG_DOT_CASE(13); AGMG_DOT_CASE(14); AGMG_DOT_CASE(15);
+    default: hipLaunchKernelGGL((k_multi_dot<16>), grid, block, 0, s, x, ys, n, seg1, gap, partials); break;
   }
+#undef AGMG_DOT_CASE
   hipLaunchKernelGGL(k_dot_final, dim3(nvec), dim3(DOT_BLOCKS), 0, s, partials, (int)g, out);
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
@@ -296,16 +293,13 @@ int vec_multi_axpy(hipStream_t s, double *y, const VecPtrs &xs, const Coeffs &a,
   if (nvec < 1 || nvec > DOT_MAX_VECS) { set_error("vec_multi_axpy: bad nvec"); return -1; }
   if (n == 0) return 0;
   const dim3 grid(grid_for(n)), block(VB);
+#define AGMG_AXPY_CASE(N) case N: hipLaunchKernelGGL((k_multi_axpy<N>), grid, block, 0, s, y, xs, a, n); break
   switch (nvec) {
-    case 1: hipLaunchKernelGGL((k_multi_axpy<1>), grid, block, 0, s, y, xs, a, n); break;
-    case 2: hipLaunchKernelGGL((k_multi_axpy<2>), grid, block, 0, s, y, xs, a, n); break;
-    case 3: hipLaunchKernelGGL((k_multi_axpy<3>), grid, block, 0, s, y, xs, a, n); break;
-    case 4: hipLaunchKernelGGL((k_multi_axpy<4>), grid, block, 0, s, y, xs, a, n); break;
-    case 5: hipLaunchKernelGGL((k_multi_axpy<5>), grid, block, 0, s, y, xs, a, n); break;
-    case 6: hipLaunchKernelGGL((k_multi_axpy<6>), grid, block, 0, s, y, xs, a, n); break;
-    case 7: hipLaunchKernelGGL((k_multi_axpy<7>), grid, block, 0, s, y, xs, a, n); break;
-    default: hipLaunchKernelGGL((k_multi_axpy<8>), grid, block, 0, s, y, xs, a, n); break;
+    AGMG_AXPY_CASE(1); AGMG_AXPY_CASE(2); AGMG_AXPY_CASE(3); AGMG_AXPY_CASE(4); AGMG_AXPY_CASE(5); AGMG_AXPY_CASE(6); AGMG_AXPY_CASE(7); AGMG_AXPY_CASE(8);
+    AGMG_AXPY_CASE(9); AGMG_AXPY_CASE(10); AGMG_AXPY_CASE(11); AGMG_AXPY_CASE(12); AGMG_AXPY_CASE(13); AGMG_AXPY_CASE(14); AGMG_AXPY_CASE(15);
+    default: hipLaunchKernelGGL((k_multi_axpy<16>), grid, block, 0, s, y, xs, a, n); break;
   }
+#undef AGMG_AXPY_CASE
   AGMG_HIP_CHECK(hipGetLastError());
   return 0;
 }
