@@ -342,6 +342,7 @@ struct agmg_ctx {
   }
   bool use_blocks = true;
   bool use_ell = true;     // assembled rows for the Q1 mass operator (AGMG_NO_ELL=1: matrix-free cell kernel + pull)
+  bool use_ell_classes = true;   // columns of the assembled rows by offset class (AGMG_NO_ELL_CLASSES=1: explicit columns)
   bool mass_ell(const DeviceLevel &lv, const CoeffData &cd) const {
     return use_ell && lv.ell_col && cd.ell_val && cd.ell_stride == lv.ell_stride;
   }
@@ -463,7 +464,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.sv.sendbuf); dfree(l.sv.recvbuf); dfree(l.sv.ypart); dfree(l.sv_shidx); dfree(l.bt_symrow);
   dfree(l.gid_v); dfree(l.gid_p);
   dfree(l.ell_col); dfree(l.coeff.ell_val); dfree(l.coeff.brick_geo);
-  dfree(l.ell_xrow); dfree(l.ell_xptr); dfree(l.ell_xent);
+  dfree(l.ell_xrow); dfree(l.ell_xptr); dfree(l.ell_xent); dfree(l.ell_cls); dfree(l.ell_cls_off);
   l = DeviceLevel();
 }
 
@@ -2544,6 +2545,7 @@ agmg_ctx *agmg_create(const agmg_options *opt) {
   if (const char *e = getenv("AGMG_NO_FUSED")) c->use_fused = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_ELL")) c->use_ell = atoi(e) == 0;
   if (const char *e = getenv("AGMG_NO_SYM")) c->use_sym = atoi(e) == 0;
+  if (const char *e = getenv("AGMG_NO_ELL_CLASSES")) c->use_ell_classes = atoi(e) == 0;
   if (const char *e = getenv("AGMG_GRAPHS")) c->use_graphs = atoi(e) != 0;
   if (const char *e = getenv("AGMG_NO_BATCHED_SETUP")) c->use_batched_setup = atoi(e) == 0;
   c->L.resize(opt->n_levels);
@@ -2815,6 +2817,31 @@ static int set_level_tables(agmg_ctx *c, DeviceLevel &lv, HostLevel &hl, int lev
           lv.ell_w = W;
           lv.ell_stride = (int)npad;
           lv.bytes_tables += col.size() * 4;
+          if (c->use_ell_classes) {
+            // classes of rows by their column offsets (structured numberings have a few dozen; give up beyond 1024)
+            std::map<std::vector<int32_t>, uint16_t> classes;
+            std::vector<uint16_t> cls(nn);
+            std::vector<int32_t> key(W), off;
+            bool few = true;
+            std::vector<int32_t> last;
+            uint16_t last_cls = 0;
+            for (int i = 0; i < nn && few; ++i) {
+              for (int k = 0; k < W; ++k) key[k] = (int32_t)col[(size_t)k * npad + i] - (int32_t)i;
+              if (key == last) { cls[i] = last_cls; continue; }   // (neighbouring rows mostly share their class)
+              auto it = classes.find(key);
+              if (it == classes.end()) {
+                if (classes.size() >= 1024) { few = false; break; }
+                it = classes.emplace(key, (uint16_t)classes.size()).first;
+                off.insert(off.end(), key.begin(), key.end());
+              }
+              cls[i] = it->second;
+              last = key; last_cls = it->second;
+            }
+            if (few) {
+              CHECK(c->upload(&lv.ell_cls, cls)); CHECK(c->upload(&lv.ell_cls_off, off));
+              lv.bytes_tables += cls.size() * 2 + off.size() * 4;
+            }
+          }
           if (!snh.empty()) {   // received shares of the owned rows other ranks ghost: entry k of the receive buffer belongs to snh[k]
             std::vector<int32_t> xrow(lv.n_owned_p, -1);
             std::vector<uint32_t> xptr(1, 0), xent(snh.size());

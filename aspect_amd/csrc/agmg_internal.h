@@ -214,6 +214,11 @@ struct DeviceLevel {
   // (unused entries point at the row's own node and carry the value 0); values live in CoeffData
   uint32_t *ell_col = nullptr;
   int ell_w = 0, ell_stride = 0;
+  // column structure by class: on a structured numbering almost every row has the columns row + (one of a few offset
+  // vectors); ell_cls[row] names the vector, ell_cls_off[class][ell_w] holds it.  nullptr: too many classes (an
+  // arbitrary numbering), the kernel reads ell_col.  Saves 4 of the 12 bytes per entry the operator moves.
+  uint16_t *ell_cls = nullptr;
+  int32_t *ell_cls_off = nullptr;
   // distributed levels: per owned pressure node its row in the CSR of received shares (-1: nobody ghosts the node)
   int32_t *ell_xrow = nullptr;
   uint32_t *ell_xptr = nullptr, *ell_xent = nullptr;

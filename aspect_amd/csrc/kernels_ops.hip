@@ -191,6 +191,9 @@ struct EllMulArgs {
   const uint32_t *sptr, *spos;
   const uint8_t *ssplit;
   const double *ypart, *srecv;
+  // columns by class (DeviceLevel::ell_cls): column k of row n = n + cls_off[cls[n]][k]
+  const uint16_t *cls;
+  const int32_t *cls_off;
 };
 struct EllSymArgs {
   const uint32_t *col;
@@ -236,8 +239,14 @@ __global__ void __launch_bounds__(256) k_mass_ell(const EllMulArgs M) {
   } else {
     uint32_t col[W];
     double val[W];
+    if (M.cls) {
+      const int32_t *off = M.cls_off + (size_t)M.cls[n] * W;
 #pragma unroll
-    for (int k = 0; k < W; ++k) { col[k] = M.col[k * st + n]; val[k] = M.val[k * st + n]; }
+      for (int k = 0; k < W; ++k) { col[k] = (uint32_t)(n + off[k]); val[k] = M.val[k * st + n]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) { col[k] = M.col[k * st + n]; val[k] = M.val[k * st + n]; }
+    }
 #pragma unroll
     for (int k = 0; k < W; ++k) sum = fma(val[k], M.src[col[k]], sum);
   }
@@ -1219,7 +1228,7 @@ int launch_mass_ell_assemble(hipStream_t s, const DeviceLevel &L, const CoeffDat
 int launch_mass_ell(hipStream_t s, const DeviceLevel &L, const CoeffData &cd, const double *src_p, const EpiArgs &e, int phase) {
   if (!L.ell_col || !cd.ell_val || cd.ell_stride != L.ell_stride) { set_error("mass rows not assembled"); return -4; }
   EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, L.ell_cls, L.ell_cls_off};
   if (phase == PH_GHOST) {
     m.node0 = L.n_owned_p; m.n_nodes = L.n_nodes_p - L.n_owned_p; m.ghost_out = L.xp.ghostbuf;
     if (m.n_nodes > 0 && !m.ghost_out) { set_error("launch_mass_ell: ghost rows without an exchange buffer"); return -1; }
@@ -1251,7 +1260,7 @@ int launch_mass_ell_sym(hipStream_t s, const DeviceLevel &L, const CoeffData &cd
   } else {
     if (L.n_nodes_p <= 0) return 0;
     const EllMulArgs m{L.ell_col, cd.ell_val, L.n_nodes_p, L.ell_stride, L.cmask_p, src_p, e, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       x.row, x.ptr, x.pos, x.split, x.ypart, x.recvbuf};
+                       x.row, x.ptr, x.pos, x.split, x.ypart, x.recvbuf, L.ell_cls, L.ell_cls_off};
     const dim3 grid((L.n_nodes_p + 255) / 256), block(256);
     if (L.dim == 3) hipLaunchKernelGGL((k_mass_ell<27>), grid, block, 0, s, m);
     else hipLaunchKernelGGL((k_mass_ell<9>), grid, block, 0, s, m);
