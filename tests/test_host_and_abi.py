@@ -272,3 +272,33 @@ def test_symmetric_exchange_plans_agree_between_ranks():
             b = partition.RankLocalProblem(case(), a, size).hier.levels[l]
             for key in ("sym_neighbors_p", "sym_offsets_p", "sym_nodes_p", "sym_neighbors_v", "sym_offsets_v", "sym_nodes_v"):
                 assert np.array_equal(getattr(L[a], key), getattr(b, key)), (l, a, key)
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
+    """include/agmg.h against the ctypes mirrors of aspect_amd/capi.py: size of every struct that crosses the ABI and the
+    offsets of the fields added last (a drift between the two would pass garbage pointers to the library)."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include <stdio.h>
+#include "agmg.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu ", sizeof(agmg_options), sizeof(agmg_level_desc), sizeof(agmg_cell_data), sizeof(agmg_face_data),
+         sizeof(agmg_solve_report), sizeof(agmg_comm));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(agmg_level_desc, n_hanging_v), offsetof(agmg_level_desc, n_copy_v),
+         offsetof(agmg_level_desc, replicated), offsetof(agmg_level_desc, sym_nodes_p), offsetof(agmg_level_desc, sym_nodes_v));
+  return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-I", inc, str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    from aspect_amd.parallel import CommStruct
+    want = [C.sizeof(capi.Options), C.sizeof(capi.LevelDesc), C.sizeof(capi.CellData), C.sizeof(capi.FaceData),
+            C.sizeof(capi.SolveReport), C.sizeof(CommStruct),
+            capi.LevelDesc.n_hanging_v.offset, capi.LevelDesc.n_copy_v.offset, capi.LevelDesc.replicated.offset,
+            capi.LevelDesc.sym_nodes_p.offset, capi.LevelDesc.sym_nodes_v.offset]
+    assert got == want, (got, want)
