@@ -452,7 +452,7 @@ void agmg_ctx::free_level(DeviceLevel &l) {
   dfree(l.pull_ptr_v); dfree(l.pull_list_v); dfree(l.pull_ptr_p); dfree(l.pull_list_p);
   dfree(l.coeff.etaT); dfree(l.inv_diag_A); dfree(l.inv_diag_M);
   dfree(l.prol_parent_v); dfree(l.prol_pos_v); dfree(l.prol_parent_p); dfree(l.prol_pos_p);
-  dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT);
+  dfree(l.inv_mult_v); dfree(l.inv_mult_p); dfree(l.childrenT); dfree(l.prol_mask_v);
   dfree(l.bt.blk_hdr); dfree(l.bt.unodes); dfree(l.bt.uent8); dfree(l.bt.lidT);
   dfree(l.bt.sh_nodes); dfree(l.bt.sh_ptr); dfree(l.bt.sh_list); dfree(l.bt.blk_order);
   dfree(l.bk.gnode); dfree(l.bk.bcell); dfree(l.bk.pidx); dfree(l.bk.fx_nodes); dfree(l.bk.fx_ptr); dfree(l.bk.fx_list);
@@ -1133,6 +1133,7 @@ int agmg_ctx::ensure_transfers() {
       // cell wide both faces of a patch are the same fine nodes and count twice)
       std::vector<double> mult(nn, 0.0);
       std::vector<int> seen(ipow(nf, dim), -1);
+      std::vector<uint32_t> own_mask(vel ? (size_t)4 * C.cstride : 0, 0u);   // (5^3 = 125 patch positions: 4 words)
       for (int p = 0; p < C.n_cells; ++p)
         for (int ch = 0; ch < nch; ++ch) {
           const uint32_t f = children[(size_t)ch * C.cstride + p];
@@ -1147,14 +1148,17 @@ int agmg_ctx::ensure_transfers() {
             }
             const uint32_t fn = cn[(size_t)f * nloc + i];
             if (seen[pidx] != p) { seen[pidx] = p; mult[fn] += 1.0; }
-            if (par[fn] == 0xFFFFFFFFu) { par[fn] = p; pos[fn] = (uint8_t)pidx; }
+            if (par[fn] == 0xFFFFFFFFu) {
+              par[fn] = p; pos[fn] = (uint8_t)pidx;
+              if (vel) own_mask[(size_t)(pidx >> 5) * C.cstride + p] |= 1u << (pidx & 31);
+            }
           }
         }
       for (int i = 0; i < nn; ++i)
         if (par[i] == 0xFFFFFFFFu) { par[i] = 0; mult[i] = 1.0; }  // node not touched by any cell
       if (dist()) CHECK(global_multiplicity(vel ? F.xv : F.xp, send_nodes_h[vel ? 0 : 1][l], mult));
       for (int i = 0; i < nn; ++i) mult[i] = 1.0 / mult[i];
-      if (vel) { CHECK(upload(&F.prol_parent_v, par)); CHECK(upload(&F.prol_pos_v, pos)); CHECK(upload(&F.inv_mult_v, mult)); }
+      if (vel) { CHECK(upload(&F.prol_parent_v, par)); CHECK(upload(&F.prol_pos_v, pos)); CHECK(upload(&F.inv_mult_v, mult)); dfree(F.prol_mask_v); CHECK(upload(&F.prol_mask_v, own_mask)); }
       else { CHECK(upload(&F.prol_parent_p, par)); CHECK(upload(&F.prol_pos_p, pos)); CHECK(upload(&F.inv_mult_p, mult)); }
       F.bytes_transfer += (size_t)nn * (4 + 1 + 8);
     }

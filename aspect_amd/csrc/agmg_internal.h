@@ -208,6 +208,8 @@ struct DeviceLevel {
   uint32_t *prol_parent_p = nullptr; uint8_t *prol_pos_p = nullptr;
   double *inv_mult_v = nullptr, *inv_mult_p = nullptr;
   uint32_t *childrenT = nullptr;   // [2^dim][cstride of level-1]: child cell ids on this level
+  uint32_t *prol_mask_v = nullptr; // [4][cstride of level-1]: bit p of a parent = it is the designated parent of the fine node at
+                                   // position p of its (2k+1)^dim velocity patch (the per-parent prolongation writes only those)
   bool has_transfer = false;
   bool mass_fusable = false;       // the level fits the one-workgroup fused mass smoother
   // assembled rows of the Q1 mass operator: column structure, ELL [ell_w][ell_stride]

@@ -116,6 +116,8 @@ struct ProlCellArgs {
   const uint32_t *parent;     // [n_fine_nodes] designated parent cell of each fine node
   const uint8_t *pos;         // [n_fine_nodes] and its position in that parent's patch (a periodic
                               // direction one or two cells wide puts a node into a patch twice)
+  const uint32_t *mask;       // [4][cstride_c]: the same designation per parent, one bit per patch position (no load
+                              // of parent[] / pos[] / the fine index for the positions another parent writes)
   const double *src;          // coarse vector
   double *dst;                // fine vector
 };
@@ -129,6 +131,9 @@ __global__ void __launch_bounds__(256) k_prolongate_cells(const ProlCellArgs A) 
   uint32_t ch[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) ch[k] = A.childrenT[(size_t)k * A.cstride_c + cell];
+  uint32_t own[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) own[k] = A.mask[(size_t)k * A.cstride_c + cell];
   double cv[NLOC];
 #pragma unroll
   for (int a = 0; a < NLOC; ++a) {
@@ -174,9 +179,11 @@ __global__ void __launch_bounds__(256) k_prolongate_cells(const ProlCellArgs A) 
         const int up0 = r0 > K ? 1 : 0, up1 = r1 > K ? 1 : 0;
         const int child = up0 | (up1 << 1) | (up2 << 2);
         const int loc = (r0 - K * up0) + N1 * (r1 - K * up1) + (DIM == 3 ? N1 * N1 * (r2 - K * up2) : 0);
-        const uint32_t fn = A.cnfT[(size_t)loc * A.cstride_f + ch[child]] & NODE_MASK;
         const int p = r0 + NF * (r1 + NF * r2);
-        if (A.parent[fn] == (uint32_t)cell && A.pos[fn] == (uint8_t)p) A.dst[(size_t)fn * NC + c] += s;
+        if ((own[p >> 5] >> (p & 31)) & 1u) {
+          const uint32_t fn = A.cnfT[(size_t)loc * A.cstride_f + ch[child]] & NODE_MASK;
+          A.dst[(size_t)fn * NC + c] += s;
+        }
       }
   }
 }
@@ -343,7 +350,7 @@ int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLe
   // (AGMG_PROL_CELLS_MIN: developer/test knob for the switch-over size, read per call)
   const char *env = getenv("AGMG_PROL_CELLS_MIN");
   const long min_cells = env ? atol(env) : 131072;   // below: too few lanes, the node-owner form wins (r5: 19 vs 100 us)
-  if (velocity && coarse.n_cells >= min_cells) {
+  if (velocity && coarse.n_cells >= min_cells && fine.prol_mask_v) {
     ProlCellArgs pc;
     pc.n_coarse_cells = coarse.n_cells;
     pc.cstride_c = coarse.cstride;
@@ -353,6 +360,7 @@ int launch_prolongate_add(hipStream_t s, const DeviceLevel &fine, const DeviceLe
     pc.cncT = coarse.cnvT;
     pc.parent = fine.prol_parent_v;
     pc.pos = fine.prol_pos_v;
+    pc.mask = fine.prol_mask_v;
     pc.src = src_coarse;
     pc.dst = dst_fine;
     const long nl = (long)coarse.n_cells * fine.dim;
